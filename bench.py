@@ -1,0 +1,182 @@
+"""Benchmark of the VQ bottleneck hot path (fused forward + EMA codebook update) on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W --workload c3|c4|c1|c2 --regime uniform|cold]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one ``VectorQuantizerEMA.forward`` in training mode (distance + argmin + gather + loss + perplexity
++ EMA update) over one resident batch of synthetic tokens.  Default workload: BASELINE config 3 per GPU
+(N=65536 tokens/GPU, K=8192, D=768); with N GPUs the tokens are sharded (weak scaling: 65536 tokens per
+rank) and the EMA statistics are all-reduced over RCCL each step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (tokens per GPU, K, D, update, description)
+    "c1": (2880, 10000, 768, True, "C1 published training shape N=2880 K=10000 fwd+EMA"),
+    "c2": (4096, 512, 768, False, "C2 N=4096 K=512 fwd only"),
+    "c3": (65536, 8192, 768, True, "C3 N=65536/GPU K=8192 D=768 fused fwd+EMA"),
+    "c4": (131072, 16384, 768, True, "C4 share N=2^20/8 per GPU K=16384 D=768 fused fwd+EMA"),
+}
+
+
+def build_state(workload, regime, rank, world, dev):
+    from t5vqvae_amd import synth
+    n, k, d, update, _ = WORKLOADS[workload]
+    w = synth.normal((k, d), 1000, 0, device=dev)
+    if regime == "uniform":                      # steady-state proxy: every code in use
+        cs = torch.full((k,), float(n * world) / k, device=dev)
+        ema_w = w * cs.unsqueeze(1)
+        x, _ = synth.clustered(n, w, 0.5, 2000 + rank)
+    else:                                        # reference cold start on N(0,1) inputs
+        cs = torch.zeros(k, device=dev)
+        ema_w = synth.normal((k, d), 1000, 1, device=dev)
+        x = synth.normal((n, d), 2000 + rank, 0, device=dev)
+    x = x.view(64, n // 64, d) if n % 64 == 0 else x.view(1, n, d)
+    return w, ema_w, cs, x
+
+
+def cpu_baseline(workload, budget_s=20.0):
+    """The oracle's faithful op-for-op path (dense one-hot, three matmuls) on the host cores, on a bounded
+    token slice of the same workload."""
+    from oracle import vq_oracle as vo
+    from t5vqvae_amd import synth
+    n, k, d, update, _ = WORKLOADS[workload]
+    ns = min(n, 8192)
+    w = synth.normal((k, d), 1000, 0)
+    cs = torch.full((k,), float(n) / k)
+    st0 = vo.VQState(w, w * cs.unsqueeze(1), cs)
+    x, _ = synth.clustered(ns, w, 0.5, 2000)
+    x = x.view(1, ns, d)
+    times = []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        for i in range(6):
+            st = st0.clone()
+            t0 = time.perf_counter()
+            vo.faithful_forward(st, x, ema=True, training=update, commitment_cost=0.25)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s and i >= 1:
+                break
+    med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {"value": ns / med, "unit": "vectors/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{ns}-token slice of the workload (K={k}, D={d}, fwd{'+EMA' if update else ''}), "
+                      f"median of {len(times[1:] or times)} calls, torch CPU fp32, {os.cpu_count()} host CPUs visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--regime", default="uniform", choices=["uniform", "cold"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from t5vqvae_amd import VectorQuantizerEMA, ops
+    from t5vqvae_amd.sharded import shard_tokens
+    n, k, d, update, desc = WORKLOADS[args.workload]
+    w, ema_w, cs, x = build_state(args.workload, args.regime, rank, world, dev)
+    mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
+    with torch.no_grad():
+        mod._embedding.weight.copy_(w)
+        mod._ema_w.copy_(ema_w)
+        mod._ema_cluster_size.copy_(cs)
+    mod.encodings = "indices"
+    mod.train(update)
+    if world > 1:
+        shard_tokens(mod)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = mod(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = mod(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * world * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # roofline of the dominant kernel (fused distance + argmin), measured live with HIP events on the
+        # stream the kernel runs on (torch's current stream is the one handed to the C ABI)
+        flat = x.reshape(-1, d)
+        wq = mod._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, wq)
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ops.dist_argmin(flat, wq, xx, ee, keys=keys)
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.dist_argmin(flat, wq, xx, ee, keys=keys)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / reps
+        flops = 2.0 * n * k * d
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        result = {
+            "metric": "quantized vectors/sec (fwd+EMA)" if update else "quantized vectors/sec (fwd)",
+            "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "D": d,
+                       "regime": args.regime, "parallelism": f"token-sharded x{world}" if world > 1 else "single GPU",
+                       "encodings": "indices (dense one-hot excluded, SURVEY 8b)"},
+            "roofline": {"bound": "mfma", "kernel": "dist_mfma_kernel (fused distance+argmin)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "kernel_ms": k_ms,
+                         "flops_per_launch": flops, "traffic": None},
+            "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

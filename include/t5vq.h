@@ -1,0 +1,155 @@
+/* t5vq.h -- C ABI of the MI355X-native (gfx950) vector-quantization bottleneck.
+ *
+ * Drop-in boundary for ONE hot path of SnowYJ/T5VQVAE: the VQ bottleneck of
+ * vqvae/vqvae.py (VectorQuantizer / VectorQuantizerEMA forward + EMA codebook update).
+ * The reference has no FFI for this path -- it is a chain of stock ATen ops inside two
+ * nn.Modules -- so each entry point below cites the lines of vqvae/vqvae.py (relative to
+ * the reference root) whose ATen chain it replaces.  The Python host (t5vqvae_amd/vqvae.py)
+ * mirrors the reference's nn.Module interface on top of these calls via ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA tensor storage) unless noted;
+ *    tensors are dense row-major fp32; indices are int64 at the boundary;
+ *  - every call enqueues work on `stream` (a hipStream_t; NULL = null stream) and returns
+ *    without synchronising; no call allocates or frees device memory -- callers bring
+ *    outputs and workspaces;
+ *  - return value: T5VQ_OK, or an error code with a thread-local message in t5vq_last_error();
+ *  - N = tokens (B*S), K = codes, D = embedding dim; D % 4 == 0 and 16-byte aligned rows.
+ *  - packed key (int64): high word = order-preserving signed image of the fp32 distance,
+ *    low word = code index; min() of keys == (min distance, then lowest index) == torch.argmin's
+ *    first-minimum rule (vqvae/vqvae.py:122).
+ */
+#ifndef T5VQ_H_
+#define T5VQ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T5VQ_OK 0
+#define T5VQ_ERR_INVALID 1 /* bad argument: null pointer, shape, alignment, unsupported D */
+#define T5VQ_ERR_HIP 2     /* a HIP runtime call or kernel launch failed */
+
+#define T5VQ_CODE_PAD 128  /* |e|^2 buffers are padded to a multiple of this, pad value +inf */
+#define T5VQ_LOSS_MSE 0
+#define T5VQ_LOSS_COSINE 1
+
+typedef void* t5vq_stream_t; /* hipStream_t */
+
+/* Library identity / diagnostics (no reference counterpart). */
+int t5vq_version(void);
+const char* t5vq_last_error(void);
+/* Length of the padded |e|^2 buffer for K codes: K rounded up to T5VQ_CODE_PAD. */
+int64_t t5vq_padded_codes(int64_t K);
+/* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens. */
+int64_t t5vq_gather_blocks(int64_t N);
+
+/* Row squared norms of two matrices in one launch.
+ * Replaces torch.sum(flat_input**2, dim=1, keepdim=True) and torch.sum(weight**2, dim=1)
+ * (vqvae/vqvae.py:106-107, :27-28, :174-175).
+ *   xx[i] = sum_d x[i,d]^2, i < N;  ee[k] = sum_d w[k,d]^2, k < K;  ee[k] = +inf, K <= k < padded(K).
+ * Either matrix may be skipped by passing rows = 0. */
+int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee,
+                         int64_t D, t5vq_stream_t stream);
+
+/* Fused distance + argmin on fp32 MFMA; the N x K distance matrix never reaches HBM.
+ * Replaces distances = (xx + ee) - 2 * matmul(x, W^T) and torch.argmin(distances, 1)
+ * (vqvae/vqvae.py:106-108,122; plain variant :27-29,43) and, when `range` is non-null, the per-token
+ * Python loop argmin(distances[i, start:end]) of the disentangled mode (:110-119, :31-40).
+ *   d_ik = fl(fl(xx_i + ee_k) - 2 * dot_ik)   (same rounding order as the reference expression)
+ *   keys[i] = min over codes of pack(d_ik, index)
+ * index = code_offset + k, or, with range != NULL ([N,2] int64 [start,end) in global code ids), the
+ * slice-relative index code_offset + k - start_i restricted to start_i <= code_offset + k < end_i --
+ * the reference uses the slice-relative argmin as an absolute row (:116-119), and so does this.
+ * code_offset is the global id of w's first row (0 unless the codebook is sharded by code).
+ * merge == 0: keys are overwritten.  merge != 0: keys already hold valid packed keys (e.g. from another
+ * codebook shard) and are min-merged.  Rows whose range misses this shard keep INT64_MAX / their old key.
+ * ee must be the padded buffer written by t5vq_row_sqnorms_f32. */
+int t5vq_dist_argmin_f32(const float* x, const float* w, const float* xx, const float* ee,
+                         const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
+                         int merge, int64_t* keys, t5vq_stream_t stream);
+
+/* Unpack keys -> indices (int64, what torch.argmin returns, vqvae/vqvae.py:122) and/or distances.
+ * Either output may be NULL. */
+int t5vq_unpack_keys(const int64_t* keys, int64_t N, int64_t* idx, float* dmin, t5vq_stream_t stream);
+
+/* Full distance matrix dist[N,K] (get_latent, vqvae/vqvae.py:167-178), same MFMA mainloop. */
+int t5vq_distances_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
+                       int64_t D, float* dist, t5vq_stream_t stream);
+
+/* Codeword gather + straight-through output + latent-loss terms + EMA statistics in one pass over x.
+ * Replaces encodings = zeros().scatter_(); quantized = matmul(encodings, W) (vqvae/vqvae.py:124-128),
+ * the loss terms (:147-152), quantized = inputs + (quantized - inputs).detach() (:160) and, for the EMA
+ * statistics, torch.sum(encodings, 0) (:133) and matmul(encodings.t(), flat_input) (:141).
+ *   idx_i   = low word of keys[i] (clamped to [0,K));   q_i = w[idx_i]
+ *   out_ste[i] = fl(x_i + fl(q_i - x_i))   (nullable)      out_q[i] = q_i (nullable, get_hidden :236)
+ *   out_diff[i] = fl(q_i - x_i)            (nullable; saved for backward)
+ *   idx_out[i] = idx_i as int64            (nullable)
+ *   counts[k - stats_begin]  = #{i : idx_i = k} as fp32  (nullable; zeroed by this call)
+ *   embed_sum[k - stats_begin,:] = sum_{i : idx_i = k} x_i (nullable; zeroed by this call; fp32 atomics,
+ *                    one flush per (workgroup, code) after an in-LDS segment sum)
+ *                    both only for stats_begin <= k < stats_begin + stats_count (the whole codebook:
+ *                    0, K; a code shard keeps statistics for its own slice only)
+ *   loss_partial[b] = per-workgroup sum of (q-x)^2 (MSE) or of 1 - cos(q_i, x_i) (COSINE, ATen
+ *                    cosine_embedding_loss form, eps 1e-12); length t5vq_gather_blocks(N) (nullable) */
+int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
+                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
+                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
+                          float* loss_partial, t5vq_stream_t stream);
+
+/* loss_sum[0] = sum of the n partials (fixed order, fp64 accumulation). */
+int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream);
+
+/* Cluster-size EMA + Laplace smoothing + loss/perplexity scalars.
+ * Replaces vqvae/vqvae.py:132-139 (mode != 0), :148/:152,:157 (loss), :161-162 (perplexity):
+ *   cs <- cs*decay + one_minus_decay*counts;  n = sum(cs);  cs <- (cs + epsilon) / (n + k_epsilon) * n
+ *   m = loss_sum / loss_denom;   loss = plain_variant ? m + commitment_cost*m : commitment_cost*m
+ *   perplexity = exp(-sum_k p_k log(p_k + 1e-10)), p_k = counts[k] / n_tokens
+ * scalars[0..3] = loss, perplexity, n (0 if mode == 0), m.   one_minus_decay and k_epsilon are passed
+ * in because the reference evaluates (1 - decay) and K*epsilon in Python double before they meet fp32.
+ * mode 0: scalars only (eval).  mode 1: update, all in one call (K = the whole codebook).
+ * Code-sharded codebooks (K = this shard's codes, k_epsilon still global K * epsilon) split the update
+ * around one scalar all-reduce:  mode 2 writes cs <- cs*decay + one_minus_decay*counts and the LOCAL
+ * partial sums scalars[1] = sum p log(p + 1e-10), scalars[2] = sum cs;  the caller all-reduces
+ * scalars[1..2];  mode 3 reads them back, applies the Laplace smoothing and writes the perplexity. */
+int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t K,
+                         int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
+                         float k_epsilon, float commitment_cost, int plain_variant, int mode, float* scalars,
+                         t5vq_stream_t stream);
+
+/* Codebook EMA: ema_w <- ema_w*decay + one_minus_decay*embed_sum;  w <- ema_w / cluster_size[:,None]
+ * (vqvae/vqvae.py:141-144; in place instead of re-binding new Parameters). */
+int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
+                       int64_t D, float decay, float one_minus_decay, t5vq_stream_t stream);
+
+/* Gradient of the straight-through output and the MSE commitment term with respect to the inputs:
+ *   grad_x = g_out - diff * (g_loss[0] * coef),  diff = q - x,  coef = commitment_cost * 2 / (N*D)
+ * (autograd of vqvae/vqvae.py:148,157,160 and :55,69,71).  g_out or g_loss may be NULL (= 0). */
+int t5vq_ste_backward_f32(const float* g_out, const float* diff, const float* g_loss, float coef,
+                          int64_t n_elems, float* grad_x, t5vq_stream_t stream);
+
+/* out[k,:] = scale * sum_{i : idx_i = k} rows[i,:]  with scale = scale_host * (scale_dev ? scale_dev[0] : 1).
+ * Plain variant's codebook gradient: rows = q - x, scale = g_loss * 2/(N*D)
+ * (autograd of matmul(encodings, W) under mse_loss, vqvae/vqvae.py:51,56).  out is zeroed by the call. */
+int t5vq_scatter_rows_f32(const float* rows, const int64_t* idx, const float* scale_dev, float scale_host,
+                          int64_t N, int64_t K, int64_t D, float* out, t5vq_stream_t stream);
+
+/* Cosine latent loss gradients (autograd of F.cosine_embedding_loss(..., reduction="sum") / B at
+ * vqvae/vqvae.py:58-64,150-152):  with c_i = 1 - cos(q_i, x_i),
+ *   grad_x[i]   = g_out[i] + s_x * dc_i/dx_i        s_x = g_loss[0] * coef_x   (coef_x = commitment_cost / B)
+ *   grad_q[i]   =            s_q * dc_i/dq_i        s_q = g_loss[0] * coef_q   (coef_q = 1 / B; plain variant)
+ * grad_q may be NULL (EMA variant); g_out may be NULL. */
+int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out, const float* g_loss,
+                             float coef_x, float coef_q, int64_t N, int64_t D, float* grad_x, float* grad_q,
+                             t5vq_stream_t stream);
+
+/* enc[N,K] = one-hot(idx) in fp32 (vqvae/vqvae.py:124-125).  Off the hot path: every caller of the
+ * reference discards it. */
+int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T5VQ_H_ */

@@ -1,0 +1,67 @@
+"""ctypes binding of the C-ABI library ``csrc/libt5vq.so`` (include/t5vq.h).
+
+There is no fallback: if the library is missing or fails to load, importing the ops raises.  The
+library is built in-tree by ``__graft_entry__.build()`` / ``make -C t5vqvae_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libt5vq.so")
+
+P = c_void_p
+I64 = c_int64
+
+# name -> (restype, argtypes); mirrors include/t5vq.h one to one
+SIGNATURES = {
+    "t5vq_version": (c_int, []),
+    "t5vq_last_error": (c_char_p, []),
+    "t5vq_padded_codes": (I64, [I64]),
+    "t5vq_gather_blocks": (I64, [I64]),
+    "t5vq_row_sqnorms_f32": (c_int, [P, I64, P, P, I64, P, I64, P]),
+    "t5vq_dist_argmin_f32": (c_int, [P, P, P, P, P, I64, I64, I64, I64, c_int, P, P]),
+    "t5vq_unpack_keys": (c_int, [P, I64, P, P, P]),
+    "t5vq_distances_f32": (c_int, [P, P, P, P, I64, I64, I64, P, P]),
+    "t5vq_gather_stats_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, P, P, P, I64, I64, P, P, P, P]),
+    "t5vq_reduce_partials_f32": (c_int, [P, I64, P, P]),
+    "t5vq_ema_cluster_f32": (c_int, [P, P, P, I64, I64, c_float, c_float, c_float, c_float, c_float, c_float,
+                                     c_int, c_int, P, P]),
+    "t5vq_ema_embed_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P]),
+    "t5vq_ste_backward_f32": (c_int, [P, P, P, c_float, I64, P, P]),
+    "t5vq_scatter_rows_f32": (c_int, [P, P, P, c_float, I64, I64, I64, P, P]),
+    "t5vq_cosine_backward_f32": (c_int, [P, P, P, P, c_float, c_float, I64, I64, P, P, P]),
+    "t5vq_one_hot_f32": (c_int, [P, I64, I64, P, P]),
+}
+
+_lib = None
+
+
+class T5VQError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library (once).  Raises if it is missing -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T5VQError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C t5vqvae_amd/csrc`.  t5vqvae_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().t5vq_last_error().decode("utf-8", "replace")
+        raise T5VQError(f"{what} failed (code {status}): {msg}")

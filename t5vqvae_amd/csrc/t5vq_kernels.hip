@@ -1,0 +1,955 @@
+// t5vq_kernels.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the VQ bottleneck.
+// See include/t5vq.h for the contract and the reference lines each entry point replaces.
+//
+// Kernel set
+//   row_sqnorms        |x|^2, |e|^2                         HBM-bound
+//   dist_mfma<..>      x.E^T on v_mfma_f32_32x32x2_f32, LDS-staged tiles, fused argmin epilogue   MFMA-bound
+//   gather_stats<..>   W[idx] gather + STE + loss terms + in-LDS segment sum -> one atomic flush   HBM/atomic-bound
+//   ema_cluster / ema_embed  EMA + Laplace smoothing                                                HBM-bound
+//   ste_backward / scatter_rows / cosine_backward / one_hot / unpack_keys
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "t5vq.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+#define T5VQ_CHECK_HIP(expr)                                                         \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) return fail(T5VQ_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define T5VQ_REQUIRE(cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) return fail(T5VQ_ERR_INVALID, "%s (%s)", msg, #cond); \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// packed keys
+// ------------------------------------------------------------------------------------------------
+constexpr long long KEY_NONE = 0x7FFFFFFFFFFFFFFFLL;
+constexpr int CODE_NONE = 0x7FFFFFFF;  // 'no admissible code seen yet' (ranged mode)
+
+__device__ __forceinline__ long long pack_key(float d, int idx) {
+    int b = __float_as_int(d);
+    int s = b >= 0 ? b : (b ^ 0x7FFFFFFF);  // signed, order-preserving image of the float
+    return (static_cast<long long>(s) << 32) | static_cast<unsigned int>(idx);
+}
+__device__ __forceinline__ float key_dist(long long key) {
+    int s = static_cast<int>(key >> 32);
+    return __int_as_float(s >= 0 ? s : (s ^ 0x7FFFFFFF));
+}
+__device__ __forceinline__ int key_index(long long key) { return static_cast<int>(key & 0xFFFFFFFFLL); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: row squared norms (one wave per row, two matrices per launch)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_sqnorms_kernel(const float* __restrict__ x, long long n_x,
+                                                          float* __restrict__ xx, const float* __restrict__ w,
+                                                          long long n_w, long long n_w_pad, float* __restrict__ ee,
+                                                          int D, long long blocks_x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const float* src;
+    float* dst;
+    long long row, n_rows, n_out;
+    if (static_cast<long long>(blockIdx.x) < blocks_x) {
+        src = x; dst = xx; n_rows = n_x; n_out = n_x;
+        row = static_cast<long long>(blockIdx.x) * 4 + wave;
+    } else {
+        src = w; dst = ee; n_rows = n_w; n_out = n_w_pad;
+        row = (static_cast<long long>(blockIdx.x) - blocks_x) * 4 + wave;
+    }
+    if (row >= n_out) return;
+    if (row >= n_rows) {
+        if (lane == 0) dst[row] = __int_as_float(0x7F800000);  // +inf: padded codes never win the argmin
+        return;
+    }
+    const f32x4* p = reinterpret_cast<const f32x4*>(src + row * D);
+    float s = 0.f;
+    for (int i = lane; i < (D >> 2); i += 64) {
+        f32x4 v = p[i];
+        s = fmaf(v.x, v.x, s);
+        s = fmaf(v.y, v.y, s);
+        s = fmaf(v.z, v.z, s);
+        s = fmaf(v.w, v.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) dst[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused distance + argmin on fp32 MFMA
+//
+// Workgroup = 256 threads = 4 waves; tile = 128 tokens x 128 codes; K-chunk (of D) = 32.
+// C[code][token] = sum_k W[code][k] * X[token][k]:  A operand = codebook rows, B operand = token rows, so in
+// the 32x32 accumulator the TOKEN sits on the lane (col = lane & 31) and 16 CODES sit in the registers
+// (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  The per-token argmin is then a register-local scan; only
+// the two lane halves are merged at the very end (one shuffle).  Wave w owns tokens [32w, 32w+32) of the
+// tile and all 128 codes: 4 independent accumulators.
+// LDS: double-buffered [128][36] fp32 images of the X and W chunks (row stride 144 B = 9 x 16 B, so the 16
+// lanes of every ds_read_b128 group hit 16 distinct 16-byte slots: conflict-free), filled through
+// registers: global loads for chunk t+1 are issued before the MFMAs of chunk t and written after them.
+// ------------------------------------------------------------------------------------------------
+constexpr int TOK_TILE = 128;
+constexpr int CODE_TILE = 128;
+constexpr int BK = 32;
+constexpr int LDS_ROW = 36;                       // floats per LDS row (32 + 4 pad)
+constexpr int LDS_IMG = 128 * LDS_ROW;            // floats per image
+constexpr int DIST_LDS_BYTES = 2 * 2 * LDS_IMG * 4;  // [buf][x|w]
+
+struct Stage {
+    f32x4 xv[4];
+    f32x4 wv[4];
+};
+
+template <bool RANGED, bool WRITE_DIST>
+__global__ __launch_bounds__(256, 2) void dist_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
+    const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
+    int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys,
+    float* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int split = blockIdx.x % n_splits;
+    const int tok_base = (blockIdx.x / n_splits) * TOK_TILE;
+    const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > n_code_tiles) tile_end = n_code_tiles;
+    const int n_tiles = tile_end - tile_begin;
+    if (n_tiles <= 0) return;
+    const int n_chunks = (D + BK - 1) / BK;
+    const int total = n_tiles * n_chunks;
+
+    // staging assignment: float4 #f = tid + 256 j  ->  row f / 8, 16-byte column f % 8
+    const int s_row = tid >> 3;       // + 32 j
+    const int s_col = (tid & 7) * 4;  // float offset inside the chunk
+    const float* xrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int t = tok_base + s_row + 32 * j;
+        if (t > N - 1) t = N - 1;
+        xrow[j] = x + static_cast<size_t>(t) * D + s_col;
+    }
+
+    auto load_stage = [&](Stage& st, int ct, int kc) {
+        const int col = kc * BK + s_col;
+        const bool in = col < D;  // D % 4 == 0, so a float4 is wholly in or out
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = (tile_begin + ct) * CODE_TILE + s_row + 32 * j;
+            if (c > K - 1) c = K - 1;
+            const float* wp = w + static_cast<size_t>(c) * D + s_col + kc * BK;
+            const float* xp = xrow[j] + kc * BK;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            st.xv[j] = in ? *reinterpret_cast<const f32x4*>(xp) : z;
+            st.wv[j] = in ? *reinterpret_cast<const f32x4*>(wp) : z;
+        }
+    };
+    auto store_stage = [&](const Stage& st, int buf) {
+        float* xs = lds + buf * (2 * LDS_IMG);
+        float* ws = xs + LDS_IMG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (s_row + 32 * j) * LDS_ROW + s_col;
+            *reinterpret_cast<f32x4*>(xs + off) = st.xv[j];
+            *reinterpret_cast<f32x4*>(ws + off) = st.wv[j];
+        }
+    };
+
+    // per-lane token data
+    const int tok = tok_base + wave * 32 + l31;
+    const int tok_c = tok < N ? tok : N - 1;
+    const float xv = xx[tok_c];
+    long long r_start = 0, r_end = 0;
+    if (RANGED) {
+        r_start = range[2 * static_cast<size_t>(tok_c)];
+        r_end = range[2 * static_cast<size_t>(tok_c) + 1];
+    }
+
+    float best = __int_as_float(0x7F800000);
+    int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;  // local code id (before code_offset)
+
+    Stage st;
+    load_stage(st, 0, 0);
+    store_stage(st, 0);
+    __syncthreads();
+
+    int it = 0;
+    for (int ct = 0; ct < n_tiles; ++ct) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        for (int kc = 0; kc < n_chunks; ++kc, ++it) {
+            const bool has_next = it + 1 < total;
+            if (has_next) {
+                int nkc = kc + 1, nct = ct;
+                if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
+                load_stage(st, nct, nkc);
+            }
+            const float* xs = lds + (it & 1) * (2 * LDS_IMG) + (wave * 32 + l31) * LDS_ROW + 4 * h;
+            const float* ws = lds + (it & 1) * (2 * LDS_IMG) + LDS_IMG + l31 * LDS_ROW + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xs + 8 * g);
+                f32x4 a[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f32x4*>(ws + t * 32 * LDS_ROW + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[j], acc[t], 0, 0, 0);
+            }
+            if (has_next) store_stage(st, (it + 1) & 1);
+            __syncthreads();
+        }
+
+        // epilogue for this code tile: d = fl(fl(xx + ee) - 2 dot), running first-minimum per token
+        const int code0 = (tile_begin + ct) * CODE_TILE + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cb = code0 + t * 32 + 8 * g4;
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(ee + cb);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int code = cb + c;
+                    const float s = xv + e4[c];
+                    float d = fmaf(-2.0f, acc[t][g4 * 4 + c], s);
+                    if (WRITE_DIST) {
+                        if (tok < N && code < K) dist[static_cast<size_t>(tok) * K + code] = d;
+                    } else {
+                        if (RANGED) {
+                            const long long gc = code_offset + code;
+                            const bool valid = gc >= r_start && gc < r_end && code < K;
+                            if (valid && (d < best || best_code == CODE_NONE)) {  // first valid code always taken
+                                best = d;
+                                best_code = code;
+                            }
+                        } else {
+                            if (d < best) {
+                                best = d;
+                                best_code = code;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (WRITE_DIST) return;
+
+    // merge the two lane halves (codes 4h + ...), lowest index wins ties
+    const float ob = __shfl_xor(best, 32);
+    const int oc = __shfl_xor(best_code, 32);
+    if (oc != CODE_NONE && (best_code == CODE_NONE || ob < best || (ob == best && oc < best_code))) {
+        best = ob;
+        best_code = oc;
+    }
+    if (h == 0 && tok < N) {
+        long long key = KEY_NONE;
+        if (best_code != CODE_NONE) {
+            long long gi = code_offset + best_code;
+            if (RANGED) gi -= r_start;  // slice-relative, as the reference returns it
+            key = pack_key(best, static_cast<int>(gi));
+        }
+        if (atomic_merge) {
+            if (key != KEY_NONE) atomicMin(keys + tok, key);
+        } else {
+            keys[tok] = key;
+        }
+    }
+}
+
+__global__ void fill_keys_kernel(long long* keys, long long n) {
+    long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = KEY_NONE;
+}
+
+__global__ void unpack_keys_kernel(const long long* __restrict__ keys, long long n, long long* __restrict__ idx,
+                                   float* __restrict__ dmin) {
+    long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long k = keys[i];
+    if (idx) idx[i] = key_index(k);
+    if (dmin) dmin[i] = key_dist(k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3: gather + STE + loss + EMA statistics.  One workgroup = 64 tokens.
+// Tokens of the workgroup that chose the same code form a group (64-bit member mask, built in LDS);
+// a wave walks a group's members in ascending token order, summing their x rows in registers, and issues
+// ONE flush of the group sum per (workgroup, code): the row is transposed through LDS so that every
+// global_atomic_add_f32 wave-instruction covers 256 contiguous bytes.
+// Lane layout inside a row: float4 #(j*64 + lane), j < NCH  (NCH = ceil(D / 256)).
+// ------------------------------------------------------------------------------------------------
+constexpr int GS_TOK = 64;
+
+template <int NCH, bool COSINE>
+__global__ __launch_bounds__(256) void gather_stats_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const long long* __restrict__ keys, int N, int K,
+    int D, float* __restrict__ out_ste, float* __restrict__ out_q, float* __restrict__ out_diff,
+    long long* __restrict__ idx_out, int stats_begin, int stats_count, float* __restrict__ counts,
+    float* __restrict__ embed_sum, float* __restrict__ loss_partial) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // [4 waves][NCH*256] transposition rows
+    __shared__ int s_code[GS_TOK];
+    __shared__ unsigned long long s_gmask[GS_TOK];
+    __shared__ int s_gcode[GS_TOK];
+    __shared__ int s_ngroups;
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tok0 = blockIdx.x * GS_TOK;
+    const int n_here = min(GS_TOK, N - tok0);
+
+    if (tid < GS_TOK) {
+        int code = -1;
+        if (tid < n_here) {
+            code = key_index(keys[tok0 + tid]);
+            code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
+            if (idx_out) idx_out[tok0 + tid] = code;
+        }
+        s_code[tid] = code;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int mine = s_code[lane];
+        unsigned long long m = 0;
+        for (int t = 0; t < GS_TOK; ++t)
+            if (s_code[t] == mine) m |= 1ull << t;
+        const bool leader = mine >= 0 && (__ffsll(static_cast<long long>(m)) - 1) == lane;
+        const unsigned long long lead_mask = __ballot(leader);
+        if (leader) {
+            const int rank = __popcll(lead_mask & ((1ull << lane) - 1ull));
+            s_gmask[rank] = m;
+            s_gcode[rank] = mine;
+            const int sc = mine - stats_begin;
+            if (counts && sc >= 0 && sc < stats_count) atomicAdd(counts + sc, static_cast<float>(__popcll(m)));
+        }
+        if (lane == 0) s_ngroups = __popcll(lead_mask);
+    }
+    __syncthreads();
+    const int n_groups = s_ngroups;
+
+    float lsum = 0.f;  // MSE: sum (q-x)^2 over this lane's columns; COSINE: lane 0 holds sum of 1 - cos
+    float* trow = tbuf + wave * (NCH * 256);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int g = wave; g < n_groups; g += 4) {
+        const int code = __builtin_amdgcn_readfirstlane(s_gcode[g]);
+        unsigned long long m = s_gmask[g];
+        f32x4 q[NCH], sum[NCH];
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(w + static_cast<size_t>(code) * D);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c4 = j * 64 + lane;
+            q[j] = (c4 * 4 < D) ? wrow[c4] : zero4;
+            sum[j] = zero4;
+        }
+        float qq = 0.f;
+        if (COSINE) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                qq += q[j].x * q[j].x + q[j].y * q[j].y + q[j].z * q[j].z + q[j].w * q[j].w;
+            qq = wave_sum(qq);
+        }
+        while (m) {
+            const int t = __ffsll(static_cast<long long>(m)) - 1;
+            m &= m - 1;
+            const size_t rowoff = static_cast<size_t>(tok0 + t) * D;
+            const f32x4* xr = reinterpret_cast<const f32x4*>(x + rowoff);
+            f32x4 xv[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c4 = j * 64 + lane;
+                xv[j] = (c4 * 4 < D) ? xr[c4] : zero4;
+            }
+            float pd = 0.f, px = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c4 = j * 64 + lane;
+                const f32x4 df = q[j] - xv[j];
+                if (c4 * 4 < D) {
+                    if (out_ste) reinterpret_cast<f32x4*>(out_ste + rowoff)[c4] = xv[j] + df;
+                    if (out_q) reinterpret_cast<f32x4*>(out_q + rowoff)[c4] = q[j];
+                    if (out_diff) reinterpret_cast<f32x4*>(out_diff + rowoff)[c4] = df;
+                }
+                if (COSINE) {
+                    pd += q[j].x * xv[j].x + q[j].y * xv[j].y + q[j].z * xv[j].z + q[j].w * xv[j].w;
+                    px += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
+                } else {
+                    lsum = fmaf(df.x, df.x, lsum);
+                    lsum = fmaf(df.y, df.y, lsum);
+                    lsum = fmaf(df.z, df.z, lsum);
+                    lsum = fmaf(df.w, df.w, lsum);
+                }
+                sum[j] += xv[j];
+            }
+            if (COSINE) {
+                pd = wave_sum(pd);
+                px = wave_sum(px);
+                const float den = sqrtf((qq + 1e-12f) * (px + 1e-12f));
+                if (lane == 0) lsum += 1.0f - pd / den;
+            }
+        }
+        const int scode = code - stats_begin;
+        if (embed_sum && scode >= 0 && scode < stats_count) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) reinterpret_cast<f32x4*>(trow)[j * 64 + lane] = sum[j];
+            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+            float* dst = embed_sum + static_cast<size_t>(scode) * D;
+#pragma unroll
+            for (int mcol = 0; mcol < NCH * 4; ++mcol) {
+                const int col = mcol * 64 + lane;
+                if (col < D) atomicAdd(dst + col, trow[col]);
+            }
+        }
+    }
+    if (loss_partial) {
+        lsum = wave_sum(lsum);
+        if (lane == 0) s_red[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) loss_partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ p, long long n,
+                                                              float* __restrict__ out) {
+    __shared__ double s[4];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) acc += static_cast<double>(p[i]);
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = static_cast<float>((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a: cluster-size EMA + Laplace smoothing + loss / perplexity scalars (one workgroup)
+// ------------------------------------------------------------------------------------------------
+__device__ double block_sum_d(double v, double* s) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < static_cast<int>(blockDim.x >> 6); ++i) t += s[i];
+    return t;
+}
+
+// mode 0: scalars only (eval).  mode 1: fused update.  mode 2: phase 1 of a code-sharded update
+// (cs <- cs*decay + omd*counts; scalars[1] = local sum p log(p+1e-10), scalars[2] = local sum cs).
+// mode 3: phase 2 (reads the all-reduced scalars[1], scalars[2]; normalises cs; writes perplexity).
+__global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ cs, const float* __restrict__ counts,
+                                                           const float* __restrict__ loss_sum, int K, float n_tokens,
+                                                           float loss_denom, float decay, float omd, float eps,
+                                                           float k_eps, float cc, int plain_variant, int mode,
+                                                           float* __restrict__ scalars) {
+    __shared__ double s[16];
+    double ent = 0.0, nsum = 0.0;
+    float n = 0.f;
+    if (mode != 3) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float c = counts[k];
+            const float p = __fdiv_rn(c, n_tokens);
+            ent += static_cast<double>(__fmul_rn(p, logf(__fadd_rn(p, 1e-10f))));
+            if (mode != 0) {
+                const float v = __fadd_rn(__fmul_rn(cs[k], decay), __fmul_rn(omd, c));
+                cs[k] = v;
+                nsum += static_cast<double>(v);
+            }
+        }
+        ent = block_sum_d(ent, s);
+        if (mode != 0) n = static_cast<float>(block_sum_d(nsum, s));
+    } else {
+        ent = static_cast<double>(scalars[1]);
+        n = scalars[2];
+        __syncthreads();  // everyone has read the scalars before thread 0 overwrites them
+    }
+    if (mode == 1 || mode == 3) {
+        const float den = __fadd_rn(n, k_eps);
+        for (int k = threadIdx.x; k < K; k += blockDim.x)  // mode 1: each thread re-reads only what it wrote
+            cs[k] = __fmul_rn(__fdiv_rn(__fadd_rn(cs[k], eps), den), n);
+    }
+    if (threadIdx.x == 0) {
+        const float m = loss_sum ? __fdiv_rn(loss_sum[0], loss_denom) : 0.f;
+        const float cm = __fmul_rn(cc, m);
+        scalars[0] = plain_variant ? __fadd_rn(m, cm) : cm;
+        scalars[1] = mode == 2 ? static_cast<float>(ent) : expf(static_cast<float>(-ent));
+        scalars[2] = n;
+        scalars[3] = m;
+    }
+}
+
+// K4b: codebook EMA, one wave per code row
+__global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
+                                                        const float* __restrict__ dw, const float* __restrict__ cs,
+                                                        int K, int D, float decay, float omd) {
+    const int lane = threadIdx.x & 63;
+    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= K) return;
+    const float c = cs[row];
+    f32x4* e = reinterpret_cast<f32x4*>(ema_w + row * D);
+    f32x4* o = reinterpret_cast<f32x4*>(w + row * D);
+    const f32x4* s = reinterpret_cast<const f32x4*>(dw + row * D);
+    for (int i = lane; i < (D >> 2); i += 64) {
+        const f32x4 a = e[i], b = s[i];
+        f32x4 v, q;
+        v.x = __fadd_rn(__fmul_rn(a.x, decay), __fmul_rn(omd, b.x));
+        v.y = __fadd_rn(__fmul_rn(a.y, decay), __fmul_rn(omd, b.y));
+        v.z = __fadd_rn(__fmul_rn(a.z, decay), __fmul_rn(omd, b.z));
+        v.w = __fadd_rn(__fmul_rn(a.w, decay), __fmul_rn(omd, b.w));
+        q.x = __fdiv_rn(v.x, c);
+        q.y = __fdiv_rn(v.y, c);
+        q.z = __fdiv_rn(v.z, c);
+        q.w = __fdiv_rn(v.w, c);
+        e[i] = v;
+        o[i] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ste_backward_kernel(const float* __restrict__ g_out,
+                                                           const float* __restrict__ diff,
+                                                           const float* __restrict__ g_loss, float coef, long long n4,
+                                                           float* __restrict__ grad_x) {
+    const float s = g_loss ? g_loss[0] * coef : 0.f;
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(diff)[i];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (g_out) g = reinterpret_cast<const f32x4*>(g_out)[i];
+        g.x = fmaf(-s, d.x, g.x);
+        g.y = fmaf(-s, d.y, g.y);
+        g.z = fmaf(-s, d.z, g.z);
+        g.w = fmaf(-s, d.w, g.w);
+        reinterpret_cast<f32x4*>(grad_x)[i] = g;
+    }
+}
+
+// scatter-add of rows by index with the same in-LDS grouping as gather_stats
+template <int NCH>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ rows,
+                                                           const long long* __restrict__ idx,
+                                                           const float* __restrict__ scale_dev, float scale_host,
+                                                           int N, int K, int D, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];
+    __shared__ int s_code[GS_TOK];
+    __shared__ unsigned long long s_gmask[GS_TOK];
+    __shared__ int s_gcode[GS_TOK];
+    __shared__ int s_ngroups;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok0 = blockIdx.x * GS_TOK;
+    const int n_here = min(GS_TOK, N - tok0);
+    const float scale = scale_host * (scale_dev ? scale_dev[0] : 1.0f);
+    if (tid < GS_TOK) {
+        int code = -1;
+        if (tid < n_here) {
+            long long c = idx[tok0 + tid];
+            code = c < 0 ? 0 : (c > K - 1 ? K - 1 : static_cast<int>(c));
+        }
+        s_code[tid] = code;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int mine = s_code[lane];
+        unsigned long long m = 0;
+        for (int t = 0; t < GS_TOK; ++t)
+            if (s_code[t] == mine) m |= 1ull << t;
+        const bool leader = mine >= 0 && (__ffsll(static_cast<long long>(m)) - 1) == lane;
+        const unsigned long long lead_mask = __ballot(leader);
+        if (leader) {
+            const int rank = __popcll(lead_mask & ((1ull << lane) - 1ull));
+            s_gmask[rank] = m;
+            s_gcode[rank] = mine;
+        }
+        if (lane == 0) s_ngroups = __popcll(lead_mask);
+    }
+    __syncthreads();
+    const int n_groups = s_ngroups;
+    float* trow = tbuf + wave * (NCH * 256);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int g = wave; g < n_groups; g += 4) {
+        const int code = __builtin_amdgcn_readfirstlane(s_gcode[g]);
+        unsigned long long m = s_gmask[g];
+        f32x4 sum[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) sum[j] = zero4;
+        while (m) {
+            const int t = __ffsll(static_cast<long long>(m)) - 1;
+            m &= m - 1;
+            const f32x4* r = reinterpret_cast<const f32x4*>(rows + static_cast<size_t>(tok0 + t) * D);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c4 = j * 64 + lane;
+                if (c4 * 4 < D) sum[j] += r[c4];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) reinterpret_cast<f32x4*>(trow)[j * 64 + lane] = sum[j] * scale;
+        float* dst = out + static_cast<size_t>(code) * D;
+#pragma unroll
+        for (int mcol = 0; mcol < NCH * 4; ++mcol) {
+            const int col = mcol * 64 + lane;
+            if (col < D) atomicAdd(dst + col, trow[col]);
+        }
+    }
+}
+
+// cosine latent-loss gradients, one wave per token row
+__global__ __launch_bounds__(256) void cosine_backward_kernel(const float* __restrict__ x, const float* __restrict__ q,
+                                                              const float* __restrict__ g_out,
+                                                              const float* __restrict__ g_loss, float coef_x,
+                                                              float coef_q, int N, int D, float* __restrict__ grad_x,
+                                                              float* __restrict__ grad_q) {
+    const int lane = threadIdx.x & 63;
+    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float gl = g_loss ? g_loss[0] : 0.f;
+    const float sx = gl * coef_x, sq = gl * coef_q;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+    const f32x4* qr = reinterpret_cast<const f32x4*>(q + row * D);
+    float pd = 0.f, px = 0.f, pq = 0.f;
+    for (int i = lane; i < (D >> 2); i += 64) {
+        const f32x4 a = qr[i], b = xr[i];
+        pd += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        pq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        px += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    pd = wave_sum(pd);
+    const float m1 = wave_sum(pq) + 1e-12f;  // |q|^2 + eps
+    const float m2 = wave_sum(px) + 1e-12f;  // |x|^2 + eps
+    const float den = sqrtf(m1 * m2);
+    // c = 1 - pd/den;  dc/dx = -q/den + pd * x / (den * m2);  dc/dq = -x/den + pd * q / (den * m1)
+    const float inv = 1.0f / den;
+    const float kx = pd * inv / m2, kq = pd * inv / m1;
+    for (int i = lane; i < (D >> 2); i += 64) {
+        const f32x4 a = qr[i], b = xr[i];
+        f32x4 gx = (b * kx - a * inv) * sx;
+        if (g_out) gx += reinterpret_cast<const f32x4*>(g_out + row * D)[i];
+        reinterpret_cast<f32x4*>(grad_x + row * D)[i] = gx;
+        if (grad_q) reinterpret_cast<f32x4*>(grad_q + row * D)[i] = (a * kq - b * inv) * sq;
+    }
+}
+
+__global__ void one_hot_kernel(const long long* __restrict__ idx, long long N, long long K, float* __restrict__ enc) {
+    long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    long long c = idx[i];
+    if (c >= 0 && c < K) enc[i * K + c] = 1.0f;
+}
+
+int pick_nch(int64_t D) {
+    const int64_t need = (D + 255) / 256;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 3) return 3;
+    if (need <= 4) return 4;
+    if (need <= 8) return 8;
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int t5vq_version(void) { return 100; }
+const char* t5vq_last_error(void) { return g_err; }
+int64_t t5vq_padded_codes(int64_t K) { return (K + T5VQ_CODE_PAD - 1) / T5VQ_CODE_PAD * T5VQ_CODE_PAD; }
+int64_t t5vq_gather_blocks(int64_t N) { return (N + GS_TOK - 1) / GS_TOK; }
+
+int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee, int64_t D,
+                         t5vq_stream_t stream) {
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
+    T5VQ_REQUIRE(N >= 0 && K >= 0, "negative row count");
+    T5VQ_REQUIRE(N == 0 || (x && xx && aligned16(x)), "x/xx null or x not 16-byte aligned");
+    T5VQ_REQUIRE(K == 0 || (w && ee && aligned16(w)), "w/ee null or w not 16-byte aligned");
+    const int64_t kpad = t5vq_padded_codes(K);
+    const int64_t bx = (N + 3) / 4, bw = (kpad + 3) / 4;
+    if (bx + bw == 0) return T5VQ_OK;
+    T5VQ_REQUIRE(bx + bw < (1LL << 31), "too many rows");
+    hipLaunchKernelGGL(row_sqnorms_kernel, dim3(static_cast<unsigned>(bx + bw)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, N, xx, w, K, kpad, ee, static_cast<int>(D), bx);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+static int launch_dist(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
+                       int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys, float* dist,
+                       hipStream_t stream) {
+    T5VQ_REQUIRE(x && w && xx && ee, "null input");
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
+    T5VQ_REQUIRE(aligned16(x) && aligned16(w) && aligned16(ee), "x, w, ee must be 16-byte aligned");
+    T5VQ_REQUIRE(N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - CODE_TILE, "N or K too large");
+    T5VQ_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
+
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    T5VQ_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<false, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<true, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
+        attr_done[dev] = true;
+    }
+
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    // Split the codebook over workgroups when token tiles alone cannot fill 256 CUs x 2 workgroups.
+    int64_t splits = 1;
+    if (!dist) {
+        while (tok_tiles * splits < 512 && splits * 2 <= code_tiles && splits < 64) splits *= 2;
+    }
+    const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
+    const int atomic = (splits > 1 || merge) ? 1 : 0;
+    if (!dist && splits > 1 && !merge) {
+        hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<long long*>(keys), static_cast<long long>(N));
+        T5VQ_CHECK_HIP(hipGetLastError());
+    }
+    const dim3 grid(static_cast<unsigned>(tok_tiles * splits));
+    const long long* rg = reinterpret_cast<const long long*>(range);
+    long long* kp = reinterpret_cast<long long*>(keys);
+    if (dist) {
+        hipLaunchKernelGGL((dist_mfma_kernel<false, true>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee, rg,
+                           static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits),
+                           static_cast<int>(tiles_per_split), static_cast<long long>(code_offset), 0, kp, dist);
+    } else if (range) {
+        hipLaunchKernelGGL((dist_mfma_kernel<true, false>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee, rg,
+                           static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits),
+                           static_cast<int>(tiles_per_split), static_cast<long long>(code_offset), atomic, kp, dist);
+    } else {
+        hipLaunchKernelGGL((dist_mfma_kernel<false, false>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee,
+                           rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D),
+                           static_cast<int>(splits), static_cast<int>(tiles_per_split),
+                           static_cast<long long>(code_offset), atomic, kp, dist);
+    }
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_dist_argmin_f32(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
+                         int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
+                         t5vq_stream_t stream) {
+    T5VQ_REQUIRE(keys, "keys is null");
+    return launch_dist(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, nullptr,
+                       static_cast<hipStream_t>(stream));
+}
+
+int t5vq_distances_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
+                       int64_t D, float* dist, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(dist, "dist is null");
+    return launch_dist(x, w, xx, ee, nullptr, N, K, D, 0, 0, nullptr, dist, static_cast<hipStream_t>(stream));
+}
+
+int t5vq_unpack_keys(const int64_t* keys, int64_t N, int64_t* idx, float* dmin, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(keys && N >= 0, "keys null or N negative");
+    if (N == 0) return T5VQ_OK;
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(keys),
+                       static_cast<long long>(N), reinterpret_cast<long long*>(idx), dmin);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
+                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
+                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
+                          float* loss_partial, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(x && w && keys, "null input");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
+    T5VQ_REQUIRE(aligned16(x) && aligned16(w), "x, w must be 16-byte aligned");
+    T5VQ_REQUIRE((!out_ste || aligned16(out_ste)) && (!out_q || aligned16(out_q)) && (!out_diff || aligned16(out_diff)),
+                 "outputs must be 16-byte aligned");
+    T5VQ_REQUIRE(loss_kind == T5VQ_LOSS_MSE || loss_kind == T5VQ_LOSS_COSINE, "unknown loss_kind");
+    const int nch = pick_nch(D);
+    T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
+    T5VQ_REQUIRE(stats_begin >= 0 && stats_count >= 0 && stats_begin + stats_count <= K, "stats slice outside [0,K)");
+    T5VQ_REQUIRE(!embed_sum || aligned16(embed_sum), "embed_sum must be 16-byte aligned");
+    if (counts && stats_count) T5VQ_CHECK_HIP(hipMemsetAsync(counts, 0, static_cast<size_t>(stats_count) * 4, stream));
+    if (embed_sum && stats_count)
+        T5VQ_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(stats_count) * D * 4, stream));
+    const dim3 grid(static_cast<unsigned>(t5vq_gather_blocks(N)));
+    const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
+    const long long* kp = reinterpret_cast<const long long*>(keys);
+    long long* ip = reinterpret_cast<long long*>(idx_out);
+#define T5VQ_GS(NCH_, COS_)                                                                                         \
+    hipLaunchKernelGGL((gather_stats_kernel<NCH_, COS_>), grid, dim3(256), lds, stream, x, w, kp,                   \
+                       static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), out_ste, out_q, out_diff, ip, \
+                       static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial)
+#define T5VQ_GS_D(COS_)                \
+    switch (nch) {                     \
+        case 1: T5VQ_GS(1, COS_); break; \
+        case 2: T5VQ_GS(2, COS_); break; \
+        case 3: T5VQ_GS(3, COS_); break; \
+        case 4: T5VQ_GS(4, COS_); break; \
+        default: T5VQ_GS(8, COS_); break; \
+    }
+    if (loss_kind == T5VQ_LOSS_COSINE) {
+        T5VQ_GS_D(true)
+    } else {
+        T5VQ_GS_D(false)
+    }
+#undef T5VQ_GS_D
+#undef T5VQ_GS
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(partials && loss_sum && n >= 0, "null pointer or negative n");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+                       static_cast<long long>(n), loss_sum);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t K,
+                         int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
+                         float k_epsilon, float commitment_cost, int plain_variant, int mode, float* scalars,
+                         t5vq_stream_t stream) {
+    T5VQ_REQUIRE(scalars && (counts || mode == 3), "counts/scalars null");
+    T5VQ_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0..3");
+    T5VQ_REQUIRE(mode == 0 || cluster_size, "cluster_size null with mode != 0");
+    T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && n_tokens > 0, "K, n_tokens out of range");
+    hipLaunchKernelGGL(ema_cluster_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cluster_size,
+                       counts, loss_sum, static_cast<int>(K), static_cast<float>(n_tokens), loss_denom, decay,
+                       one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, mode, scalars);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
+                       int64_t D, float decay, float one_minus_decay, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(ema_w && w && embed_sum && cluster_size, "null pointer");
+    T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0 && D % 4 == 0, "K, D out of range");
+    T5VQ_REQUIRE(aligned16(ema_w) && aligned16(w) && aligned16(embed_sum), "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(ema_embed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),
+                       static_cast<int>(D), decay, one_minus_decay);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_ste_backward_f32(const float* g_out, const float* diff, const float* g_loss, float coef, int64_t n_elems,
+                          float* grad_x, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(diff && grad_x, "null pointer");
+    T5VQ_REQUIRE(n_elems > 0 && n_elems % 4 == 0, "n_elems must be a positive multiple of 4");
+    T5VQ_REQUIRE(aligned16(diff) && aligned16(grad_x) && (!g_out || aligned16(g_out)), "16-byte alignment");
+    const long long n4 = n_elems / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ste_backward_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), g_out, diff, g_loss, coef, n4, grad_x);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_scatter_rows_f32(const float* rows, const int64_t* idx, const float* scale_dev, float scale_host, int64_t N,
+                          int64_t K, int64_t D, float* out, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(rows && idx && out, "null pointer");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0 && aligned16(rows), "D % 4 and alignment");
+    const int nch = pick_nch(D);
+    T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
+    T5VQ_CHECK_HIP(hipMemsetAsync(out, 0, static_cast<size_t>(K) * D * 4, stream));
+    const dim3 grid(static_cast<unsigned>(t5vq_gather_blocks(N)));
+    const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
+    const long long* ip = reinterpret_cast<const long long*>(idx);
+#define T5VQ_SC(NCH_)                                                                                            \
+    hipLaunchKernelGGL((scatter_rows_kernel<NCH_>), grid, dim3(256), lds, stream, rows, ip, scale_dev, scale_host, \
+                       static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), out)
+    switch (nch) {
+        case 1: T5VQ_SC(1); break;
+        case 2: T5VQ_SC(2); break;
+        case 3: T5VQ_SC(3); break;
+        case 4: T5VQ_SC(4); break;
+        default: T5VQ_SC(8); break;
+    }
+#undef T5VQ_SC
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out, const float* g_loss, float coef_x,
+                             float coef_q, int64_t N, int64_t D, float* grad_x, float* grad_q,
+                             t5vq_stream_t stream) {
+    T5VQ_REQUIRE(x && q && grad_x, "null pointer");
+    T5VQ_REQUIRE(N > 0 && N < (1LL << 31) && D > 0 && D % 4 == 0, "N, D out of range");
+    T5VQ_REQUIRE(aligned16(x) && aligned16(q) && aligned16(grad_x) && (!grad_q || aligned16(grad_q)) &&
+                     (!g_out || aligned16(g_out)), "16-byte alignment");
+    hipLaunchKernelGGL(cosine_backward_kernel, dim3(static_cast<unsigned>((N + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, q, g_out, g_loss, coef_x, coef_q, static_cast<int>(N),
+                       static_cast<int>(D), grad_x, grad_q);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(idx && enc && N > 0 && K > 0, "null pointer or empty shape");
+    T5VQ_CHECK_HIP(hipMemsetAsync(enc, 0, static_cast<size_t>(N) * K * 4, stream));
+    hipLaunchKernelGGL(one_hot_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const long long*>(idx), static_cast<long long>(N), static_cast<long long>(K),
+                       enc);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+}  // extern "C"

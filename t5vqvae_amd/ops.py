@@ -1,0 +1,216 @@
+"""Tensor-level wrappers of the C ABI (include/t5vq.h): argument checks, output/workspace allocation
+(torch's caching allocator: plumbing), launch on torch's current HIP stream.  No arithmetic happens
+here; every function enqueues kernels and returns without synchronising.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+LOSS_KINDS = {"mse": 0, "cosine": 1}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str, dtype=torch.float32, ndim: Optional[int] = None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device (got {t.device}); t5vqvae_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def padded_codes(k: int) -> int:
+    return int(_lib.load().t5vq_padded_codes(k))
+
+
+def gather_blocks(n: int) -> int:
+    return int(_lib.load().t5vq_gather_blocks(n))
+
+
+def row_sqnorms(x: Optional[torch.Tensor], w: Optional[torch.Tensor]):
+    """(xx [N], ee [padded(K)]) -- either input may be None."""
+    lib = _lib.load()
+    ref = x if x is not None else w
+    d = ref.shape[1]
+    xx = ee = None
+    n = k = 0
+    if x is not None:
+        _need(x, "x", ndim=2)
+        n = x.shape[0]
+        xx = torch.empty(n, dtype=torch.float32, device=x.device)
+    if w is not None:
+        _need(w, "w", ndim=2)
+        k = w.shape[0]
+        ee = torch.empty(padded_codes(k), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.t5vq_row_sqnorms_f32(_p(x), n, _p(xx), _p(w), k, _p(ee), d, _stream(ref)), "row_sqnorms")
+    return xx, ee
+
+
+def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merge: bool = False):
+    """Packed (distance, index) keys [N] int64 of the nearest codeword per token."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d or xx.shape[0] != n or ee.shape[0] != padded_codes(k):
+        raise RuntimeError("dist_argmin: inconsistent shapes")
+    if ranges is not None:
+        _need(ranges, "ranges", torch.int64, 2)
+        if tuple(ranges.shape) != (n, 2):
+            raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
+    if keys is None:
+        if merge:
+            raise RuntimeError("merge=True needs existing keys")
+        keys = torch.empty(n, dtype=torch.int64, device=x.device)
+    else:
+        _need(keys, "keys", torch.int64, 1)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_dist_argmin_f32(_p(x), _p(w), _p(xx), _p(ee), _p(ranges), n, k, d, code_offset,
+                                            1 if merge else 0, _p(keys), _stream(x)), "dist_argmin")
+    return keys
+
+
+def unpack_keys(keys, want_idx=True, want_dmin=False):
+    lib = _lib.load()
+    _need(keys, "keys", torch.int64, 1)
+    n = keys.shape[0]
+    idx = torch.empty(n, dtype=torch.int64, device=keys.device) if want_idx else None
+    dmin = torch.empty(n, dtype=torch.float32, device=keys.device) if want_dmin else None
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.t5vq_unpack_keys(_p(keys), n, _p(idx), _p(dmin), _stream(keys)), "unpack_keys")
+    return idx, dmin
+
+
+def distances(x, w, xx, ee):
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
+    n, d = x.shape
+    k = w.shape[0]
+    out = torch.empty(n, k, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_distances_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, _p(out), _stream(x)), "distances")
+    return out
+
+
+def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, idx=None, counts=None,
+                 embed_sum=None, loss_partial=None, stats_begin: int = 0, stats_count: Optional[int] = None):
+    """Every output is optional and caller-allocated (None = not produced)."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(keys, "keys", torch.int64, 1)
+    n, d = x.shape
+    k = w.shape[0]
+    if stats_count is None:
+        stats_count = k - stats_begin
+    for name, t, shape in (("ste", ste, (n, d)), ("q", q, (n, d)), ("diff", diff, (n, d)),
+                           ("counts", counts, (stats_count,)), ("embed_sum", embed_sum, (stats_count, d)),
+                           ("loss_partial", loss_partial, (gather_blocks(n),))):
+        if t is not None:
+            _need(t, name)
+            if t.numel() != int(torch.Size(shape).numel()):
+                raise RuntimeError(f"{name}: expected {shape}, got {tuple(t.shape)}")
+    if idx is not None:
+        _need(idx, "idx", torch.int64)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_gather_stats_f32(_p(x), _p(w), _p(keys), n, k, d, LOSS_KINDS[loss], _p(ste), _p(q),
+                                             _p(diff), _p(idx), stats_begin, stats_count, _p(counts),
+                                             _p(embed_sum), _p(loss_partial), _stream(x)), "gather_stats")
+
+
+def reduce_partials(partials, out):
+    lib = _lib.load()
+    _need(partials, "partials"), _need(out, "out")
+    with torch.cuda.device(partials.device):
+        _lib.check(lib.t5vq_reduce_partials_f32(_p(partials), partials.numel(), _p(out), _stream(partials)),
+                   "reduce_partials")
+
+
+def ema_cluster(cluster_size, counts, loss_sum, k: int, n_tokens: int, loss_denom: float, decay: float,
+                one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float, plain_variant: bool,
+                mode: int, scalars):
+    lib = _lib.load()
+    _need(scalars, "scalars")
+    with torch.cuda.device(scalars.device):
+        _lib.check(lib.t5vq_ema_cluster_f32(_p(cluster_size), _p(counts), _p(loss_sum), k, n_tokens, loss_denom,
+                                            decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
+                                            1 if plain_variant else 0, mode, _p(scalars), _stream(scalars)),
+                   "ema_cluster")
+
+
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: float):
+    lib = _lib.load()
+    _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum, "embed_sum"), _need(cluster_size, "cs")
+    k, d = ema_w.shape
+    with torch.cuda.device(w.device):
+        _lib.check(lib.t5vq_ema_embed_f32(_p(ema_w), _p(w), _p(embed_sum), _p(cluster_size), k, d, decay,
+                                          one_minus_decay, _stream(w)), "ema_embed")
+
+
+def ste_backward(g_out, diff, g_loss, coef: float):
+    lib = _lib.load()
+    _need(diff, "diff")
+    if g_out is not None:
+        g_out = _need(g_out.contiguous(), "g_out")
+    if g_loss is not None:
+        g_loss = _need(g_loss.contiguous(), "g_loss")
+    out = torch.empty_like(diff)
+    with torch.cuda.device(diff.device):
+        _lib.check(lib.t5vq_ste_backward_f32(_p(g_out), _p(diff), _p(g_loss), coef, diff.numel(), _p(out),
+                                             _stream(diff)), "ste_backward")
+    return out
+
+
+def scatter_rows(rows, idx, k: int, scale_dev=None, scale_host: float = 1.0):
+    lib = _lib.load()
+    _need(rows, "rows", ndim=2), _need(idx, "idx", torch.int64)
+    n, d = rows.shape
+    out = torch.empty(k, d, dtype=torch.float32, device=rows.device)
+    if scale_dev is not None:
+        scale_dev = _need(scale_dev.contiguous(), "scale_dev")
+    with torch.cuda.device(rows.device):
+        _lib.check(lib.t5vq_scatter_rows_f32(_p(rows), _p(idx), _p(scale_dev), scale_host, n, k, d, _p(out),
+                                             _stream(rows)), "scatter_rows")
+    return out
+
+
+def cosine_backward(x, q, g_out, g_loss, coef_x: float, coef_q: float, want_grad_q: bool):
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(q, "q", ndim=2)
+    n, d = x.shape
+    if g_out is not None:
+        g_out = _need(g_out.contiguous(), "g_out")
+    if g_loss is not None:
+        g_loss = _need(g_loss.contiguous(), "g_loss")
+    gx = torch.empty_like(x)
+    gq = torch.empty_like(x) if want_grad_q else None
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_cosine_backward_f32(_p(x), _p(q), _p(g_out), _p(g_loss), coef_x, coef_q, n, d, _p(gx),
+                                                _p(gq), _stream(x)), "cosine_backward")
+    return gx, gq
+
+
+def one_hot(idx, k: int):
+    lib = _lib.load()
+    _need(idx, "idx", torch.int64)
+    n = idx.numel()
+    enc = torch.empty(n, k, dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(lib.t5vq_one_hot_f32(_p(idx), n, k, _p(enc), _stream(idx)), "one_hot")
+    return enc

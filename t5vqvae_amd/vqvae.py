@@ -1,0 +1,225 @@
+"""Drop-in ``VectorQuantizer`` / ``VectorQuantizerEMA`` for the reference's ``vqvae/vqvae.py``.
+
+Same constructor signatures (vqvae/vqvae.py:7, :80), same ``forward(inputs, srl=None)`` returning
+``(loss, quantized, perplexity, encodings)`` (:76, :165), same attributes and ``state_dict`` keys
+(``_embedding.weight``, ``_ema_w``, ``_ema_cluster_size``), same train/eval gate (``self.training``
+only, :131), same ``get_latent / get_indices / get_hidden`` (:167-238).  All arithmetic runs in the
+hand-written HIP kernels behind ``include/t5vq.h``; this file only orders the launches and keeps
+autograd informed.  There is no CPU path: tensors must live on a ROCm device.
+
+Differences that are visible and deliberate:
+* EMA state is updated in place under ``no_grad`` instead of re-binding fresh Parameters
+  (:132,137,142,144) -- identical values, stable tensor identities for optimizers/checkpoints.
+* ``encodings`` (the 4th return value, discarded by every caller of the reference) is the dense fp32
+  one-hot by default; set ``module.encodings = "indices"`` to get the ``[N, 1]`` int64 indices instead and
+  skip the N x K materialisation (the benchmark does).
+* ``process_group`` / ``world tokens``: see ``t5vqvae_amd/sharded.py``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class _Plan:
+    """Per-call configuration handed to the autograd function (plain Python, no tensors)."""
+    __slots__ = ("ema", "training", "cc", "decay", "eps", "loss", "batch", "group", "world_tokens", "module")
+
+
+def _scalar_of(buf: torch.Tensor, i: int) -> torch.Tensor:
+    """0-dim tensor over element i of ``buf`` that is NOT an autograd view (callers may do ``loss += ...``
+    on it, which a view created inside a custom Function would refuse), and costs no kernel."""
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset() + i, ())
+
+
+class _VQFunction(torch.autograd.Function):
+    """(flat inputs [N,D], codebook [K,D]) -> (loss, straight-through output, perplexity, indices)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, ranges, plan: _Plan):
+        mod = plan.module
+        w = weight.detach()
+        n, d = x.shape
+        k = w.shape[0]
+        dev = x.device
+        need_gx = ctx.needs_input_grad[0]
+        need_gw = ctx.needs_input_grad[1] and not plan.ema
+        update = plan.ema and plan.training
+
+        xx, ee = ops.row_sqnorms(x, w)
+        keys = ops.dist_argmin(x, w, xx, ee, ranges)
+
+        # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
+        # token-sharded run all-reduces in ONE collective (sharded.py)
+        kd = k * d if update else 0
+        stats = torch.empty(kd + k + 4, dtype=torch.float32, device=dev)
+        embed_sum = stats[:kd].view(k, d) if update else None
+        counts = stats[kd:kd + k]
+        loss_sum = stats[kd + k:kd + k + 1]
+        partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
+        ste = torch.empty_like(x)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        mse = plan.loss == "mse"
+        diff = torch.empty_like(x) if ((need_gx or need_gw) and mse) else None
+        q = torch.empty_like(x) if ((need_gx or need_gw) and not mse) else None
+        ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+                         embed_sum=embed_sum, loss_partial=partial)
+        ops.reduce_partials(partial, loss_sum)
+
+        n_total = n
+        batch = plan.batch
+        if plan.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=plan.group)
+            world = dist.get_world_size(plan.group)
+            n_total = plan.world_tokens if plan.world_tokens else n * world
+            batch = batch * world
+
+        scalars = torch.empty(4, dtype=torch.float32, device=dev)
+        denom = float(n_total * d) if mse else float(batch)
+        ops.ema_cluster(mod._ema_cluster_size if update else None, counts, loss_sum, k, n_total, denom,
+                        plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema,
+                        1 if update else 0, scalars)
+        if update:
+            # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
+            ops.ema_embed(mod._ema_w.data, mod._embedding.weight.data, embed_sum, mod._ema_cluster_size,
+                          plan.decay, 1 - plan.decay)
+
+        ctx.plan = plan
+        ctx.dims = (n_total, d, k, batch)
+        ctx.need_gw = need_gw
+        ctx.save_for_backward(diff, q, x if not mse else None, idx)
+        loss, ppl = _scalar_of(scalars, 0), _scalar_of(scalars, 1)
+        ctx.mark_non_differentiable(ppl, idx)
+        mod._last_scalars = scalars
+        return loss, ste, ppl, idx
+
+    @staticmethod
+    def backward(ctx, g_loss, g_ste, g_ppl, g_idx):
+        diff, q, x, idx = ctx.saved_tensors
+        plan = ctx.plan
+        n_total, d, k, batch = ctx.dims
+        gx = gw = None
+        if plan.loss == "mse":
+            if ctx.needs_input_grad[0]:
+                gx = ops.ste_backward(g_ste, diff, g_loss, plan.cc * 2.0 / (n_total * d))
+            if ctx.need_gw:
+                gw = ops.scatter_rows(diff, idx, k, scale_dev=g_loss, scale_host=2.0 / (n_total * d)) \
+                    if g_loss is not None else torch.zeros(k, d, dtype=torch.float32, device=diff.device)
+        else:
+            gx_, gq = ops.cosine_backward(x, q, g_ste, g_loss, plan.cc / batch, 1.0 / batch, ctx.need_gw)
+            if ctx.needs_input_grad[0]:
+                gx = gx_
+            if ctx.need_gw:
+                gw = ops.scatter_rows(gq, idx, k)
+        return gx, gw, None, None
+
+
+class _QuantizerBase(nn.Module):
+    _is_ema = False
+    encodings = "dense"          # "dense": fp32 one-hot [N,K] (reference behaviour) | "indices": int64 [N,1]
+    process_group = None         # set by sharded.TokenSharded*: all-reduce the EMA statistics over this group
+    world_tokens = 0             # global token count when ranks hold unequal shares (0 = n_local * world)
+
+    def _flatten(self, inputs, srl):
+        flat = inputs.view(-1, self._embedding_dim)          # same view rule as vqvae/vqvae.py:103
+        if flat.dtype != torch.float32:
+            raise RuntimeError(f"inputs must be float32 (got {flat.dtype}); the reference path is fp32")
+        ranges = None
+        if self.disentanglement:
+            ranges = srl.view(-1, 2)                         # vqvae/vqvae.py:111
+            if ranges.dtype != torch.int64:
+                ranges = ranges.to(torch.int64)
+            ranges = ranges.contiguous()
+        return flat.contiguous(), ranges
+
+    def _check_loss_name(self):
+        if self.loss not in ops.LOSS_KINDS:
+            exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
+
+    def forward(self, inputs, srl=None):
+        self._check_loss_name()
+        flat, ranges = self._flatten(inputs, srl)
+        plan = _Plan()
+        plan.ema, plan.training = self._is_ema, self.training
+        plan.cc = float(self._commitment_cost)
+        plan.decay = float(getattr(self, "_decay", 0.0))
+        plan.eps = float(getattr(self, "_epsilon", 0.0))
+        plan.loss, plan.batch = self.loss, int(inputs.shape[0])
+        plan.group, plan.world_tokens, plan.module = self.process_group, int(self.world_tokens), self
+        weight = self._embedding.weight if not self._is_ema else self._embedding.weight.detach()
+        loss, ste, ppl, idx = _VQFunction.apply(flat, weight, ranges, plan)
+        self.last_indices = idx
+        quantized = ste.view(inputs.shape)
+        if self.encodings == "dense":
+            enc = ops.one_hot(idx, self._num_embeddings)     # vqvae/vqvae.py:124-125
+        else:
+            enc = idx.unsqueeze(1)
+        return loss, quantized, ppl, enc
+
+    # --- evaluation helpers (vqvae/vqvae.py:167-238) -------------------------------------------------
+    @torch.no_grad()
+    def get_latent(self, inputs):
+        flat = inputs.view(-1, self._embedding_dim).contiguous()
+        w = self._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, w)
+        return ops.distances(flat, w, xx, ee)
+
+    @torch.no_grad()
+    def _keys(self, inputs, srl):
+        flat, ranges = self._flatten(inputs, srl)
+        w = self._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, w)
+        return flat, w, ops.dist_argmin(flat, w, xx, ee, ranges)
+
+    @torch.no_grad()
+    def get_indices(self, inputs, srl=None):
+        _, _, keys = self._keys(inputs, srl)
+        return ops.unpack_keys(keys)[0].unsqueeze(1)
+
+    @torch.no_grad()
+    def get_hidden(self, inputs, srl=None):
+        flat, w, keys = self._keys(inputs, srl)
+        q = torch.empty_like(flat)
+        ops.gather_stats(flat, w, keys, "mse", q=q)
+        return q.view(inputs.shape)
+
+
+class VectorQuantizer(_QuantizerBase):
+    """Codebook learned by gradient (vqvae/vqvae.py:6-76).  ``**kwargs`` are accepted and ignored, as in the
+    reference (train_t5.py:322 passes ``decay=`` and the role dict here)."""
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost, disentanglement=False, loss="mse", **kwargs):
+        super().__init__()
+        self._embedding_dim = embedding_dim
+        self._num_embeddings = num_embeddings
+        self._embedding = nn.Embedding(self._num_embeddings, self._embedding_dim)
+        self._embedding.weight.data.uniform_(-1 / self._num_embeddings, 1 / self._num_embeddings)  # :14
+        self._commitment_cost = commitment_cost
+        self.disentanglement = disentanglement
+        self.loss = loss
+
+
+class VectorQuantizerEMA(_QuantizerBase):
+    """Codebook learned by exponential moving averages (vqvae/vqvae.py:79-165)."""
+    _is_ema = True
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay, epsilon=1e-5, disentanglement=False,
+                 loss="mse", **kwargs):
+        super().__init__()
+        self._embedding_dim = embedding_dim
+        self._num_embeddings = num_embeddings
+        self._embedding = nn.Embedding(self._num_embeddings, self._embedding_dim)
+        self._embedding.weight.data.normal_()                                          # :87
+        self._commitment_cost = commitment_cost
+        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))         # :90
+        self._ema_w = nn.Parameter(torch.Tensor(num_embeddings, self._embedding_dim))  # :91
+        self._ema_w.data.normal_()                                                     # :92 (independent draw)
+        self._decay = decay
+        self._epsilon = epsilon
+        self.disentanglement = disentanglement
+        self.loss = loss

@@ -1,0 +1,94 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares; argument
+validation that returns before any device work; the modules keep the reference's Python contract."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "t5vq.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(t5vq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from t5vqvae_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/t5vq.h but not exported"
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    assert lib.t5vq_version() >= 100
+    assert lib.t5vq_padded_codes(10000) == 10112 and lib.t5vq_padded_codes(128) == 128
+    assert lib.t5vq_gather_blocks(65) == 2
+
+
+def test_invalid_arguments_are_rejected_before_any_launch():
+    from t5vqvae_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.t5vq_row_sqnorms_f32(p, 4, p, p, 4, p, 6, None) == 1          # D % 4 != 0
+    assert b"multiple of 4" in lib.t5vq_last_error()
+    assert lib.t5vq_dist_argmin_f32(None, p, p, p, None, 4, 4, 8, 0, 0, p, None) == 1
+    assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 8, 7, None, None, None, None, 0, 4, None, None, None, None) == 1
+    assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 4096, 0, None, None, None, None, 0, 4, None, None, None,
+                                     None) == 1                               # D > 2048
+    assert lib.t5vq_ema_cluster_f32(None, p, None, 4, 4, 1.0, .99, .01, 1e-5, 4e-5, .25, 0, 9, p, None) == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from t5vqvae_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libt5vq.so")
+    with pytest.raises(_lib.T5VQError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_module_contract_matches_reference_signatures():
+    from t5vqvae_amd import VectorQuantizer, VectorQuantizerEMA
+    # vqvae/vqvae.py:7 and :80
+    assert list(inspect.signature(VectorQuantizer.__init__).parameters) == [
+        "self", "num_embeddings", "embedding_dim", "commitment_cost", "disentanglement", "loss", "kwargs"]
+    assert list(inspect.signature(VectorQuantizerEMA.__init__).parameters) == [
+        "self", "num_embeddings", "embedding_dim", "commitment_cost", "decay", "epsilon", "disentanglement", "loss",
+        "kwargs"]
+    torch.manual_seed(0)
+    m = VectorQuantizerEMA(num_embeddings=32, embedding_dim=8, commitment_cost=0.25, decay=0.99,
+                           disentanglement=False, loss="mse", V=(0, 10), residual=(10, 32))
+    assert list(m.state_dict()) == ["_ema_w", "_ema_cluster_size", "_embedding.weight"]
+    assert [n for n, _ in m.named_parameters()] == ["_ema_w", "_embedding.weight"]
+    assert isinstance(m._ema_w, torch.nn.Parameter) and isinstance(m._embedding, torch.nn.Embedding)
+    assert m._num_embeddings == 32 and m._embedding_dim == 8 and m._epsilon == 1e-5 and m._decay == 0.99
+    assert float(m._ema_cluster_size.abs().sum()) == 0.0
+    assert not torch.equal(m._ema_w.data, m._embedding.weight.data)      # independent draws (:87, :92)
+    p = VectorQuantizer(32, 8, 0.25, decay=0.99, loss="mse", V=(0, 10))  # decay= swallowed (train_t5.py:322)
+    assert list(p.state_dict()) == ["_embedding.weight"]
+    assert float(p._embedding.weight.abs().max()) <= 1 / 32
+    assert m._embedding(torch.tensor([1, 2])).shape == (2, 8)            # callable nn.Embedding (t5/load_t5.py:488)
+
+
+def test_no_cpu_path_and_wrong_loss_name():
+    from t5vqvae_amd import VectorQuantizerEMA
+    m = VectorQuantizerEMA(16, 8, 0.25, decay=0.99)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 3, 8))
+    m.loss = "huber"
+    with pytest.raises(SystemExit):                                      # vqvae/vqvae.py:155
+        m(torch.zeros(2, 3, 8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "t5vqvae_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,211 @@
+"""HIP path vs the CPU oracle on seeded inputs (sizes the oracle finishes in seconds), edge shapes, and
+size-independent properties at the BASELINE sizes.  Everything goes through the C ABI (ctypes)."""
+import pytest
+import torch
+
+from oracle import vq_oracle as vo
+from t5vqvae_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    den = float(b.norm())
+    return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+
+def make_ema(k, d, seed, dev="cuda", **kw):
+    from t5vqvae_amd import VectorQuantizerEMA
+    m = VectorQuantizerEMA(k, d, 0.25, decay=0.99, **kw).to(dev)
+    w, e = synth.normal((k, d), seed, 0), synth.normal((k, d), seed, 1)
+    with torch.no_grad():
+        m._embedding.weight.copy_(w)
+        m._ema_w.copy_(e)
+    m.encodings = "indices"
+    return m, vo.VQState(w.clone(), e.clone(), torch.zeros(k))
+
+
+def check_step(m, st, x, srl=None, training=True, disent=False, loss="mse"):
+    """One forward on both sides; index band check; downstream tensors against the oracle evaluated with the
+    kernel's own indices when some rows fall inside the band."""
+    d = x.shape[-1]
+    m.train(training)
+    w_before = st.weight.clone()
+    lo, q, ppl, idx = m(x.cuda(), None if srl is None else srl.cuda())
+    idx = idx.squeeze(1).cpu()
+    ref = vo.algorithmic_forward(st.clone(), x, srl, ema=True, training=training, commitment_cost=0.25,
+                                 disentanglement=disent, loss=loss)
+    outside, inside = vo.classify_mismatches(x.reshape(-1, d), w_before, idx, ref.indices,
+                                             srl if disent else None)
+    assert outside == 0, f"{outside} index mismatches outside the band ({inside} inside)"
+    o = vo.algorithmic_forward(st, x, srl, ema=True, training=training, commitment_cost=0.25,
+                               disentanglement=disent, loss=loss, indices=idx)   # mutates st like the module
+    assert rel(q, o.quantized) <= TOL
+    assert rel(lo, o.loss) <= TOL
+    assert rel(ppl, o.perplexity) <= TOL
+    if training:
+        assert rel(m._ema_cluster_size, st.cluster_size) <= TOL
+        assert rel(m._ema_w.data, st.ema_w) <= TOL
+        assert rel(m._embedding.weight.data, st.weight) <= TOL
+    return inside
+
+
+@pytest.mark.parametrize("n,k,d", [(4096, 512, 768),      # C2
+                                   (2880, 10000, 768),    # C1: K not a multiple of any tile
+                                   (1, 7, 768),           # single token, tiny codebook
+                                   (130, 129, 64),        # tile edges + small D
+                                   (257, 1000, 100),      # D % 32 != 0
+                                   (63, 300, 2048)])      # widest supported row
+def test_ema_two_steps_vs_oracle(n, k, d):
+    m, st = make_ema(k, d, 7)
+    for t in range(2):
+        x = synth.normal((n, d), 8, t).view(1, n, d)
+        check_step(m, st, x)
+
+
+def test_eval_mode_leaves_buffers_untouched():
+    m, st = make_ema(512, 768, 3)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    check_step(m, st, synth.normal((4, 26, 768), 4, 0), training=False)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+
+
+def test_disentangled_straddling_ranges():
+    k, d, n = 1000, 768, 515
+    roles = [(0, 130), (130, 131), (131, 700), (700, 1000), (5, 995)]
+    m, st = make_ema(k, d, 5, disentanglement=True)
+    for t in range(2):
+        x = synth.normal((1, n, d), 6, t)
+        srl = synth.role_ranges(n, roles, 6, 40 + t).view(1, n, 2)
+        check_step(m, st, x, srl, disent=True)
+
+
+def test_cosine_loss_vs_oracle():
+    m, st = make_ema(512, 768, 9, loss="cosine")
+    check_step(m, st, synth.normal((4, 26, 768), 10, 0), loss="cosine")
+
+
+def test_exact_duplicates_pick_lowest_index():
+    k, d = 640, 768
+    m, st = make_ema(k, d, 11)
+    with torch.no_grad():
+        for dup in (130, 257, 639):          # duplicates in other tiles / lane halves / registers
+            m._embedding.weight[dup] = m._embedding.weight[3]
+            st.weight[dup] = st.weight[3]
+        m._embedding.weight[36] = m._embedding.weight[35]
+        st.weight[36] = st.weight[35]
+    x = st.weight[torch.tensor([3, 130, 257, 639, 35, 36, 100])].clone().view(1, 7, d)
+    m.eval()
+    idx = m(x.cuda())[3].squeeze(1).cpu()
+    assert idx.tolist() == [3, 3, 3, 3, 35, 35, 100]
+
+
+def test_determinism_same_input_twice():
+    m, _ = make_ema(2048, 768, 12)
+    m.eval()
+    x = synth.normal((1, 3000, 768), 13, 0).cuda()
+    a = m(x)
+    b = m(x)
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_full_size_c3_vs_oracle():
+    """BASELINE config 3 (N=65536, K=8192) in the 'uniform' regime, whole step against the oracle."""
+    n, k, d = 65536, 8192, 768
+    from t5vqvae_amd import VectorQuantizerEMA
+    w = synth.normal((k, d), 21, 0)
+    cs = torch.full((k,), n / k)
+    m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda()
+    with torch.no_grad():
+        m._embedding.weight.copy_(w)
+        m._ema_w.copy_(w * cs.unsqueeze(1))
+        m._ema_cluster_size.copy_(cs)
+    m.encodings = "indices"
+    st = vo.VQState(w.clone(), w * cs.unsqueeze(1), cs.clone())
+    x, c = synth.clustered(n, w, 0.5, 22)
+    inside = check_step(m, st, x.view(64, 1024, d))
+    print("C3 in-band mismatches:", inside)
+
+
+def test_full_size_properties_c3():
+    """Size-independent properties at N=65536, K=8192: exact codewords round-trip, histogram mass,
+    embed-sum mass, idempotence."""
+    n, k, d = 65536, 8192, 768
+    m, st = make_ema(k, d, 31)
+    w = st.weight
+    c = synth.uniform_int(n, k, 32)
+    x = w.index_select(0, c).view(1, n, d).cuda()
+    m.train(True)
+    loss, q, ppl, idx = m(x)
+    assert torch.equal(idx.squeeze(1).cpu(), c)              # every token sits exactly on its codeword
+    assert float(loss) == 0.0 and torch.equal(q, x)
+    counts = torch.bincount(c, minlength=k).float()
+    cs_expected = counts * (1 - 0.99)
+    nsum = cs_expected.sum()
+    cs_expected = (cs_expected + 1e-5) / (nsum + k * 1e-5) * nsum
+    assert rel(m._ema_cluster_size, cs_expected) <= TOL
+    # idempotence on the updated codebook: quantising codewords returns them
+    m.eval()
+    x2 = m._embedding.weight.data[:4096].clone().view(1, 4096, d)
+    finite = torch.isfinite(x2).all(-1).squeeze(0)
+    _, q2, _, idx2 = m(x2)
+    assert torch.equal(q2[0][finite], x2[0][finite])
+
+
+def test_methods_and_encodings_modes():
+    m, st = make_ema(512, 768, 41)
+    x = synth.normal((1, 45, 768), 42, 0)
+    lat = m.get_latent(x.cuda())
+    assert lat.shape == (45, 512)
+    assert rel(lat, vo.get_latent(st, x)) <= TOL
+    gi = m.get_indices(x.cuda())
+    assert gi.shape == (45, 1) and gi.dtype == torch.int64
+    assert torch.equal(gi.cpu(), vo.get_indices(st, x))
+    assert torch.equal(m.get_hidden(x.cuda()).cpu(), vo.get_hidden(st, x))
+    m.encodings = "dense"
+    m.eval()
+    enc = m(x.cuda())[3]
+    assert enc.shape == (45, 512) and enc.dtype == torch.float32
+    assert torch.equal(enc.argmax(1).cpu(), gi.squeeze(1).cpu()) and float(enc.sum()) == 45.0
+
+
+def test_autograd_plain_and_ema():
+    from t5vqvae_amd import VectorQuantizer
+    k, d = 300, 768
+    w = synth.normal((k, d), 51, 0) * 0.05
+    x = synth.normal((2, 70, d), 52, 0)
+    gq = synth.normal((2, 70, d), 53, 0)
+    m = VectorQuantizer(k, d, 0.25, decay=0.99).cuda()
+    with torch.no_grad():
+        m._embedding.weight.copy_(w)
+    xg = x.cuda().requires_grad_(True)
+    loss, q, _, _ = m(xg)
+    (loss * 1.3 + (q * gq.cuda()).sum()).backward()
+    st = vo.VQState(w.clone().requires_grad_(True))
+    xc = x.clone().requires_grad_(True)
+    o = vo.faithful_forward(st, xc, ema=False, training=True, commitment_cost=0.25)
+    (o.loss * 1.3 + (o.quantized * gq).sum()).backward()
+    assert rel(loss, o.loss) <= TOL and rel(xg.grad, xc.grad) <= TOL
+    assert rel(m._embedding.weight.grad, st.weight.grad) <= TOL
+    # `loss += ...` style in-place use by a caller must work
+    loss2, _, _, _ = m(xg)
+    loss2 += 1.0
+
+
+def test_state_dict_round_trip_and_inplace_identity():
+    m, _ = make_ema(256, 768, 61)
+    ids = {k: v.data_ptr() for k, v in m.state_dict().items()}
+    m.train()
+    m(synth.normal((1, 100, 768), 62, 0).cuda())
+    sd = m.state_dict()
+    assert set(sd) == {"_embedding.weight", "_ema_w", "_ema_cluster_size"}
+    assert all(sd[k].data_ptr() == ids[k] for k in sd)       # updated in place, not re-bound
+    from t5vqvae_amd import VectorQuantizerEMA
+    m2 = VectorQuantizerEMA(256, 768, 0.25, decay=0.99).cuda()
+    m2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    x = synth.normal((1, 50, 768), 63, 0).cuda()
+    m.eval(), m2.eval()
+    assert torch.equal(m(x)[1], m2(x)[1])
