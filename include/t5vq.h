@@ -113,7 +113,8 @@ int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, 
  * Code-sharded codebooks (K = this shard's codes, k_epsilon still global K * epsilon) split the update
  * around one scalar all-reduce:  mode 2 writes cs <- cs*decay + one_minus_decay*counts and the LOCAL
  * partial sums scalars[1] = sum p log(p + 1e-10), scalars[2] = sum cs;  the caller all-reduces
- * scalars[1..2];  mode 3 reads them back, applies the Laplace smoothing and writes the perplexity. */
+ * scalars[1..2];  mode 3 reads them back, applies the Laplace smoothing and writes the perplexity.
+ * In modes 2 and 3 cluster_size may be NULL (evaluation: only the perplexity is assembled). */
 int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t K,
                          int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
                          float k_epsilon, float commitment_cost, int plain_variant, int mode, float* scalars,

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
             const float c = counts[k];
             const float p = __fdiv_rn(c, n_tokens);
             ent += static_cast<double>(__fmul_rn(p, logf(__fadd_rn(p, 1e-10f))));
-            if (mode != 0) {
+            if (mode != 0 && cs) {
                 const float v = __fadd_rn(__fmul_rn(cs[k], decay), __fmul_rn(omd, c));
                 cs[k] = v;
                 nsum += static_cast<double>(v);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
         n = scalars[2];
         __syncthreads();  // everyone has read the scalars before thread 0 overwrites them
     }
-    if (mode == 1 || mode == 3) {
+    if ((mode == 1 || mode == 3) && cs) {
         const float den = __fadd_rn(n, k_eps);
         for (int k = threadIdx.x; k < K; k += blockDim.x)  // mode 1: each thread re-reads only what it wrote
             cs[k] = __fmul_rn(__fdiv_rn(__fadd_rn(cs[k], eps), den), n);
@@ -865,7 +865,7 @@ int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* 
                          t5vq_stream_t stream) {
     T5VQ_REQUIRE(scalars && (counts || mode == 3), "counts/scalars null");
     T5VQ_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0..3");
-    T5VQ_REQUIRE(mode == 0 || cluster_size, "cluster_size null with mode != 0");
+    T5VQ_REQUIRE(mode != 1 || cluster_size, "cluster_size null with mode 1");
     T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && n_tokens > 0, "K, n_tokens out of range");
     hipLaunchKernelGGL(ema_cluster_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cluster_size,
                        counts, loss_sum, static_cast<int>(K), static_cast<float>(n_tokens), loss_denom, decay,

@@ -42,61 +42,20 @@ class _VQFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, ranges, plan: _Plan):
         mod = plan.module
-        w = weight.detach()
-        n, d = x.shape
-        k = w.shape[0]
-        dev = x.device
         need_gx = ctx.needs_input_grad[0]
         need_gw = ctx.needs_input_grad[1] and not plan.ema
-        update = plan.ema and plan.training
-
-        xx, ee = ops.row_sqnorms(x, w)
-        keys = ops.dist_argmin(x, w, xx, ee, ranges)
-
-        # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
-        # token-sharded run all-reduces in ONE collective (sharded.py)
-        kd = k * d if update else 0
-        stats = torch.empty(kd + k + 4, dtype=torch.float32, device=dev)
-        embed_sum = stats[:kd].view(k, d) if update else None
-        counts = stats[kd:kd + k]
-        loss_sum = stats[kd + k:kd + k + 1]
-        partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
-        ste = torch.empty_like(x)
-        idx = torch.empty(n, dtype=torch.int64, device=dev)
         mse = plan.loss == "mse"
-        diff = torch.empty_like(x) if ((need_gx or need_gw) and mse) else None
-        q = torch.empty_like(x) if ((need_gx or need_gw) and not mse) else None
-        ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
-                         embed_sum=embed_sum, loss_partial=partial)
-        ops.reduce_partials(partial, loss_sum)
-
-        n_total = n
-        batch = plan.batch
-        if plan.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=plan.group)
-            world = dist.get_world_size(plan.group)
-            n_total = plan.world_tokens if plan.world_tokens else n * world
-            batch = batch * world
-
-        scalars = torch.empty(4, dtype=torch.float32, device=dev)
-        denom = float(n_total * d) if mse else float(batch)
-        ops.ema_cluster(mod._ema_cluster_size if update else None, counts, loss_sum, k, n_total, denom,
-                        plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema,
-                        1 if update else 0, scalars)
-        if update:
-            # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
-            ops.ema_embed(mod._ema_w.data, mod._embedding.weight.data, embed_sum, mod._ema_cluster_size,
-                          plan.decay, 1 - plan.decay)
-
+        r = mod._launch(x, weight.detach(), ranges, plan, want_diff=(need_gx or need_gw) and mse,
+                        want_q=(need_gx or need_gw) and not mse)
         ctx.plan = plan
-        ctx.dims = (n_total, d, k, batch)
+        ctx.dims = r["dims"]                      # (global tokens, D, rows of the codebook gradient, batch)
         ctx.need_gw = need_gw
-        ctx.save_for_backward(diff, q, x if not mse else None, idx)
+        ctx.save_for_backward(r["diff"], r["q"], x if not mse else None, r["idx"])
+        scalars = r["scalars"]
         loss, ppl = _scalar_of(scalars, 0), _scalar_of(scalars, 1)
-        ctx.mark_non_differentiable(ppl, idx)
+        ctx.mark_non_differentiable(ppl, r["idx"])
         mod._last_scalars = scalars
-        return loss, ste, ppl, idx
+        return loss, r["ste"], ppl, r["idx"]
 
     @staticmethod
     def backward(ctx, g_loss, g_ste, g_ppl, g_idx):
@@ -140,6 +99,54 @@ class _QuantizerBase(nn.Module):
     def _check_loss_name(self):
         if self.loss not in ops.LOSS_KINDS:
             exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
+
+    def _launch(self, x, w, ranges, plan, want_diff, want_q):
+        """Order the kernels of one call (single GPU, or token-sharded when ``plan.group`` is set)."""
+        n, d = x.shape
+        k = w.shape[0]
+        dev = x.device
+        update = plan.ema and plan.training
+        mse = plan.loss == "mse"
+
+        xx, ee = ops.row_sqnorms(x, w)
+        keys = ops.dist_argmin(x, w, xx, ee, ranges)
+
+        # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
+        # token-sharded run all-reduces in ONE collective (sharded.py)
+        kd = k * d if update else 0
+        stats = torch.empty(kd + k + 4, dtype=torch.float32, device=dev)
+        embed_sum = stats[:kd].view(k, d) if update else None
+        counts = stats[kd:kd + k]
+        loss_sum = stats[kd + k:kd + k + 1]
+        partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
+        ste = torch.empty_like(x)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        diff = torch.empty_like(x) if want_diff else None
+        q = torch.empty_like(x) if want_q else None
+        ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+                         embed_sum=embed_sum, loss_partial=partial)
+        ops.reduce_partials(partial, loss_sum)
+
+        n_total = n
+        batch = plan.batch
+        if plan.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(stats[:kd + k + 1], op=dist.ReduceOp.SUM, group=plan.group)
+            world = dist.get_world_size(plan.group)
+            n_total = plan.world_tokens if plan.world_tokens else n * world
+            batch = batch * world
+
+        scalars = torch.empty(4, dtype=torch.float32, device=dev)
+        denom = float(n_total * d) if mse else float(batch)
+        ops.ema_cluster(self._ema_cluster_size if update else None, counts, loss_sum, k, n_total, denom,
+                        plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema,
+                        1 if update else 0, scalars)
+        if update:
+            # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
+            ops.ema_embed(self._ema_w.data, self._embedding.weight.data, embed_sum, self._ema_cluster_size,
+                          plan.decay, 1 - plan.decay)
+        return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q,
+                "dims": (n_total, d, k, batch)}
 
     def forward(self, inputs, srl=None):
         self._check_loss_name()

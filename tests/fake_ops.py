@@ -1,0 +1,168 @@
+"""CPU stand-in for ``t5vqvae_amd.ops`` -- TEST INFRASTRUCTURE ONLY.
+
+The host logic (launch order, statistics-buffer layout, collectives, cluster modes, autograd wiring) is
+exercised without a GPU by monkeypatching ``t5vqvae_amd.vqvae.ops`` with this module inside a test.  Each
+function restates the CONTRACT of the C-ABI entry point of the same name (include/t5vq.h) with torch CPU
+ops.  The product never selects this module by itself.
+"""
+import torch
+
+LOSS_KINDS = {"mse": 0, "cosine": 1}
+KEY_NONE = 0x7FFFFFFFFFFFFFFF
+
+
+def padded_codes(k):
+    return (k + 127) // 128 * 128
+
+
+def gather_blocks(n):
+    return (n + 63) // 64
+
+
+def row_sqnorms(x, w):
+    xx = None if x is None else (x * x).sum(1)
+    ee = None
+    if w is not None:
+        ee = torch.full((padded_codes(w.shape[0]),), float("inf"))
+        ee[:w.shape[0]] = (w * w).sum(1)
+    return xx, ee
+
+
+def _pack(d, idx):
+    b = d.contiguous().view(torch.int32).to(torch.int64)
+    s = torch.where(b >= 0, b, b ^ 0x7FFFFFFF)
+    return (s << 32) | (idx.to(torch.int64) & 0xFFFFFFFF)
+
+
+def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False):
+    k = w.shape[0]
+    d = (xx.unsqueeze(1) + ee[:k]) - 2 * (x @ w.t())
+    gid = torch.arange(k).unsqueeze(0) + code_offset
+    if ranges is not None:
+        ok = (gid >= ranges[:, :1]) & (gid < ranges[:, 1:2])
+        d = torch.where(ok, d, torch.full_like(d, float("inf")))
+        any_ok = ok.any(1)
+        # first admissible code wins ties / all-inf rows
+        first_ok = torch.where(ok, gid.expand_as(ok), torch.full_like(gid.expand_as(ok), 1 << 40)).min(1).values
+    loc = torch.argmin(d, dim=1)
+    dmin = d.gather(1, loc.unsqueeze(1)).squeeze(1)
+    gi = loc + code_offset
+    if ranges is not None:
+        gi = torch.where(torch.isinf(dmin) & any_ok, first_ok, gi) - ranges[:, 0]
+    new = _pack(dmin, gi)
+    if ranges is not None:
+        new = torch.where(any_ok, new, torch.full_like(new, KEY_NONE))
+    if keys is None:
+        return new
+    if merge:
+        keys.copy_(torch.minimum(keys, new))
+    else:
+        keys.copy_(new)
+    return keys
+
+
+def unpack_keys(keys, want_idx=True, want_dmin=False):
+    idx = (keys & 0xFFFFFFFF) if want_idx else None
+    dmin = None
+    if want_dmin:
+        s = (keys >> 32).to(torch.int32)
+        dmin = torch.where(s >= 0, s, s ^ 0x7FFFFFFF).view(torch.float32)
+    return idx, dmin
+
+
+def distances(x, w, xx, ee):
+    return (xx.unsqueeze(1) + ee[:w.shape[0]]) - 2 * (x @ w.t())
+
+
+def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
+                 loss_partial=None, stats_begin=0, stats_count=None):
+    n, d = x.shape
+    k = w.shape[0]
+    if stats_count is None:
+        stats_count = k - stats_begin
+    i = (keys & 0xFFFFFFFF).clamp(0, k - 1)
+    qq = w.index_select(0, i)
+    df = qq - x
+    if ste is not None:
+        ste.copy_(x + df)
+    if q is not None:
+        q.copy_(qq)
+    if diff is not None:
+        diff.copy_(df)
+    if idx is not None:
+        idx.copy_(i)
+    local = i - stats_begin
+    inside = (local >= 0) & (local < stats_count)
+    if counts is not None:
+        counts.copy_(torch.bincount(local[inside], minlength=stats_count).float())
+    if embed_sum is not None:
+        embed_sum.zero_().index_add_(0, local[inside], x[inside])
+    if loss_partial is not None:
+        if loss == "mse":
+            per = (df * df).sum(1)
+        else:
+            per = 1 - (qq * x).sum(1) / (((qq * qq).sum(1) + 1e-12) * ((x * x).sum(1) + 1e-12)).sqrt()
+        pad = torch.zeros(gather_blocks(n) * 64)
+        pad[:n] = per
+        loss_partial.copy_(pad.view(-1, 64).sum(1))
+
+
+def reduce_partials(partials, out):
+    out[0] = partials.double().sum().float()
+
+
+def ema_cluster(cluster_size, counts, loss_sum, k, n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                commitment_cost, plain_variant, mode, scalars):
+    f = lambda v: torch.tensor(v, dtype=torch.float32)
+    if mode != 3:
+        p = counts / f(float(n_tokens))
+        ent = (p * torch.log(p + 1e-10)).double().sum()
+        n = f(0.0)
+        if mode != 0 and cluster_size is not None:
+            cluster_size.copy_(cluster_size * f(decay) + f(one_minus_decay) * counts)
+            n = cluster_size.double().sum().float()
+    else:
+        ent = scalars[1].double().clone()
+        n = scalars[2].clone()
+    if mode in (1, 3) and cluster_size is not None:
+        cluster_size.copy_((cluster_size + f(epsilon)) / (n + f(k_epsilon)) * n)
+    m = loss_sum[0] / f(loss_denom) if loss_sum is not None else f(0.0)
+    cm = f(commitment_cost) * m
+    scalars[0] = m + cm if plain_variant else cm
+    scalars[1] = ent.float() if mode == 2 else torch.exp(-ent.float())
+    scalars[2] = n
+    scalars[3] = m
+
+
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay):
+    f = lambda v: torch.tensor(v, dtype=torch.float32)
+    ema_w.copy_(ema_w * f(decay) + f(one_minus_decay) * embed_sum)
+    w.copy_(ema_w / cluster_size.unsqueeze(1))
+
+
+def ste_backward(g_out, diff, g_loss, coef):
+    s = (g_loss * coef) if g_loss is not None else 0.0
+    g = -diff * s
+    return g if g_out is None else g + g_out
+
+
+def scatter_rows(rows, idx, k, scale_dev=None, scale_host=1.0):
+    out = torch.zeros(k, rows.shape[1]).index_add_(0, idx.clamp(0, k - 1), rows)
+    return out * (scale_host * (float(scale_dev) if scale_dev is not None else 1.0))
+
+
+def cosine_backward(x, q, g_out, g_loss, coef_x, coef_q, want_grad_q):
+    gl = float(g_loss) if g_loss is not None else 0.0
+    pd = (q * x).sum(1, keepdim=True)
+    m1 = (q * q).sum(1, keepdim=True) + 1e-12
+    m2 = (x * x).sum(1, keepdim=True) + 1e-12
+    inv = 1.0 / (m1 * m2).sqrt()
+    gx = (x * (pd * inv / m2) - q * inv) * (gl * coef_x)
+    if g_out is not None:
+        gx = gx + g_out
+    gq = (q * (pd * inv / m1) - x * inv) * (gl * coef_q) if want_grad_q else None
+    return gx, gq
+
+
+def one_hot(idx, k):
+    return torch.zeros(idx.numel(), k).scatter_(1, idx.view(-1, 1), 1)

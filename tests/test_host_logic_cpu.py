@@ -1,0 +1,172 @@
+"""Host logic without a GPU: the modules' launch order, autograd wiring and multi-GPU exchanges, driven with
+``tests/fake_ops.py`` patched in for the kernel layer.  Multi-rank cases run world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fake_ops
+import golden_cases as gc
+from oracle import vq_oracle as vo
+from t5vqvae_amd import synth
+
+TOL = 1e-5
+
+
+def _patch():
+    import t5vqvae_amd.vqvae as v
+    v.ops = fake_ops
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    den = float(b.norm())
+    return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+
+@pytest.mark.parametrize("name", ["G1_ema_train3", "G3_plain_bwd", "G4_ema_roles2", "G4b_plain_roles5", "G5_ties",
+                                  "G6_ema_cosine", "G6b_plain_cosine", "G7b_methods_roles", "G11_small_dim"])
+def test_module_choreography_on_golden(name, monkeypatch):
+    import t5vqvae_amd
+    import t5vqvae_amd.vqvae as v
+    monkeypatch.setattr(v, "ops", fake_ops)
+    case = gc.CASES[name]
+    got = gc.run_case(case, lambda cls, **kw: getattr(t5vqvae_amd, cls)(**kw), "cpu")
+    exp = gc.load_case(name)
+    assert set(got) == set(exp)
+    for key in sorted(exp):
+        if key.endswith("_idx") or key.endswith("_get_indices"):
+            assert np.array_equal(got[key].numpy().ravel(), exp[key]["full"].ravel()), key
+        else:
+            assert gc.compare(got[key], exp[key]) <= TOL, key
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    _patch()
+
+
+K, D, N = 256, 64, 600
+
+
+def _reference_run(steps, roles=None, training=True):
+    w, e = synth.normal((K, D), 1, 0), synth.normal((K, D), 1, 1)
+    st = vo.VQState(w.clone(), e.clone(), torch.zeros(K))
+    outs = []
+    for t in range(steps):
+        x = synth.normal((4, N // 4, D), 2, t)
+        srl = synth.role_ranges(N, roles, 3, t).view(4, N // 4, 2) if roles else None
+        w_before = st.weight.clone()
+        o = vo.faithful_forward(st, x, srl, ema=True, training=training, commitment_cost=0.25,
+                                disentanglement=roles is not None)
+        o.extra["q_raw"] = w_before.index_select(0, o.indices).view(x.shape)
+        outs.append(o)
+    return st, outs
+
+
+def _token_sharded_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from t5vqvae_amd import VectorQuantizerEMA
+    from t5vqvae_amd.sharded import shard_tokens, broadcast_state
+    m = VectorQuantizerEMA(K, D, 0.25, decay=0.99)
+    with torch.no_grad():
+        if rank == 0:
+            m._embedding.weight.copy_(synth.normal((K, D), 1, 0))
+            m._ema_w.copy_(synth.normal((K, D), 1, 1))
+    broadcast_state(m)
+    shard_tokens(m)
+    m.train()
+    st, outs = _reference_run(2)
+    errs = []
+    for t in range(2):
+        x = synth.normal((4, N // 4, D), 2, t)
+        xs = x[rank * 2:(rank + 1) * 2].clone().requires_grad_(True)       # batch rows 0-1 / 2-3
+        loss, qz, ppl, enc = m(xs)
+        (loss * 1.5 + qz.sum()).backward()
+        o = outs[t]
+        errs += [rel(loss, o.loss), rel(ppl, o.perplexity),
+                 rel(qz, o.quantized[rank * 2:(rank + 1) * 2])]
+        assert torch.equal(enc.argmax(1), o.indices.view(4, -1)[rank * 2:(rank + 1) * 2].reshape(-1))
+        # gradient of the GLOBAL-mean commitment loss w.r.t. the local tokens (q_raw = the step's quantized)
+        xl = x[rank * 2:(rank + 1) * 2]
+        g_ref = 1.0 + 1.5 * 0.25 * 2.0 * (xl - o.extra["q_raw"][rank * 2:(rank + 1) * 2]) / (N * D)
+        errs.append(rel(xs.grad, g_ref))
+    errs += [rel(m._ema_cluster_size, st.cluster_size), rel(m._ema_w.data, st.ema_w),
+             rel(m._embedding.weight.data, st.weight)]
+    # replicas must be bit-identical
+    for tns in m.state_dict().values():
+        other = [torch.empty_like(tns) for _ in range(world)]
+        dist.all_gather(other, tns)
+        assert all(torch.equal(o_, other[0]) for o_ in other)
+    q.put((rank, max(errs)))
+    dist.destroy_process_group()
+
+
+def _code_sharded_worker(rank, world, port, q, roles, training):
+    _init(rank, world, port)
+    from t5vqvae_amd.sharded import CodeShardedVectorQuantizerEMA
+    m = CodeShardedVectorQuantizerEMA(K, D, 0.25, decay=0.99, disentanglement=roles is not None)
+    m.load_full_state_dict({"_embedding.weight": synth.normal((K, D), 1, 0), "_ema_w": synth.normal((K, D), 1, 1),
+                            "_ema_cluster_size": torch.zeros(K)})
+    m.train(training)
+    st, outs = _reference_run(2, roles, training)
+    errs = []
+    for t in range(2):
+        x = synth.normal((4, N // 4, D), 2, t)
+        srl = synth.role_ranges(N, roles, 3, t).view(4, N // 4, 2) if roles else None
+        if t == 1:
+            w_full = m.full_state_dict()["_embedding.weight"]
+            stt = vo.VQState(w_full)
+            assert rel(m.get_latent(x), vo.get_latent(stt, x)) <= TOL
+            assert torch.equal(m.get_indices(x, srl), vo.get_indices(stt, x, srl, roles is not None))
+            assert rel(m.get_hidden(x, srl), vo.get_hidden(stt, x, srl, roles is not None)) <= TOL
+        loss, qz, ppl, enc = m(x, srl)
+        o = outs[t]
+        assert torch.equal(enc.argmax(1), o.indices), f"step {t}"
+        errs += [rel(loss, o.loss), rel(ppl, o.perplexity), rel(qz, o.quantized)]
+    full = m.full_state_dict()
+    errs += [rel(full["_ema_cluster_size"], st.cluster_size), rel(full["_ema_w"], st.ema_w),
+             rel(full["_embedding.weight"], st.weight)]
+    q.put((rank, max(errs)))
+    dist.destroy_process_group()
+
+
+def _run(worker, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q) + args) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert set(res) == {0, 1}
+    assert max(res.values()) <= TOL, res
+
+
+def test_token_sharded_equals_single_process_gloo():
+    _run(_token_sharded_worker)
+
+
+@pytest.mark.parametrize("roles,training", [(None, True), (None, False),
+                                            ([(0, 128), (128, 256)], True),          # ranges aligned to shards
+                                            ([(0, 50), (50, 200), (120, 256), (3, 5)], True)])  # straddling
+def test_code_sharded_equals_single_process_gloo(roles, training):
+    _run(_code_sharded_worker, roles, training)
