@@ -41,6 +41,9 @@ typedef void* t5vq_stream_t; /* hipStream_t */
 /* Library identity / diagnostics (no reference counterpart). */
 int t5vq_version(void);
 const char* t5vq_last_error(void);
+/* Diagnostic: select a tile configuration of the distance kernel (0 = shipped default; other values only
+ * exist in builds made with -DT5VQ_TUNING and otherwise fall back to the default).  No reference counterpart. */
+int t5vq_set_tuning(int variant);
 /* Length of the padded |e|^2 buffer for K codes: K rounded up to T5VQ_CODE_PAD. */
 int64_t t5vq_padded_codes(int64_t K);
 /* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens. */

@@ -19,6 +19,7 @@ I64 = c_int64
 SIGNATURES = {
     "t5vq_version": (c_int, []),
     "t5vq_last_error": (c_char_p, []),
+    "t5vq_set_tuning": (c_int, [c_int]),
     "t5vq_padded_codes": (I64, [I64]),
     "t5vq_gather_blocks": (I64, [I64]),
     "t5vq_row_sqnorms_f32": (c_int, [P, I64, P, P, I64, P, I64, P]),

@@ -121,24 +121,49 @@ __global__ __launch_bounds__(256) void row_sqnorms_kernel(const float* __restric
 // registers: global loads for chunk t+1 are issued before the MFMAs of chunk t and written after them.
 // ------------------------------------------------------------------------------------------------
 constexpr int TOK_TILE = 128;
-constexpr int CODE_TILE = 128;
-constexpr int BK = 32;
-constexpr int LDS_ROW = 36;                       // floats per LDS row (32 + 4 pad)
-constexpr int LDS_IMG = 128 * LDS_ROW;            // floats per image
-constexpr int DIST_LDS_BYTES = 2 * 2 * LDS_IMG * 4;  // [buf][x|w]
 
-struct Stage {
-    f32x4 xv[4];
-    f32x4 wv[4];
+// Tile configuration: NT = 32-code sub-tiles per workgroup tile (code tile = 32 NT), BKC = floats of D per
+// LDS stage, PF = register double-buffering of the LDS fragments, MINW = waves per SIMD asked of the
+// register allocator (= workgroups per CU here).
+template <int NT_, int BKC_, bool PF_, int MINW_, int ABL_ = 0>
+struct DistCfg {
+    static constexpr int ABL = ABL_;  // timing-only ablations (tuning builds): 1 no staging, 2 +no barrier, 3 +no LDS reads
+    static constexpr int NT = NT_;
+    static constexpr int BKC = BKC_;
+    static constexpr bool PF = PF_;
+    static constexpr int MINW = MINW_;
+    static constexpr int CODE_TILE = 32 * NT_;
+    static constexpr int ROW = BKC_ + 4;                   // LDS row stride in floats: (BKC+4)*4 B = odd x 16 B
+    static constexpr int X_IMG = TOK_TILE * ROW;           // floats
+    static constexpr int W_IMG = CODE_TILE * ROW;
+    static constexpr int STAGE = X_IMG + W_IMG;
+    static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    static constexpr int F4_PER_ROW = BKC_ / 4;
+    static constexpr int XV = TOK_TILE * F4_PER_ROW / 256;   // float4 per thread per stage
+    static constexpr int WV = CODE_TILE * F4_PER_ROW / 256;
+    static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;   // rows covered by one float4 per thread
+    static constexpr int G = BKC_ / 8;                       // k-groups of 8 per stage
 };
 
-template <bool RANGED, bool WRITE_DIST>
-__global__ __launch_bounds__(256, 2) void dist_mfma_kernel(
+template <class C>
+struct Stage {
+    f32x4 xv[C::XV];
+    f32x4 wv[C::WV];
+};
+template <class C>
+struct Frag {
+    f32x4 b;
+    f32x4 a[C::NT];
+};
+
+template <class C, bool RANGED, bool WRITE_DIST>
+__global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
     const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
     int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys,
     float* __restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,43 +179,43 @@ __global__ __launch_bounds__(256, 2) void dist_mfma_kernel(
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
     const int n_tiles = tile_end - tile_begin;
     if (n_tiles <= 0) return;
-    const int n_chunks = (D + BK - 1) / BK;
+    const int n_chunks = (D + BKC - 1) / BKC;
     const int total = n_tiles * n_chunks;
 
-    // staging assignment: float4 #f = tid + 256 j  ->  row f / 8, 16-byte column f % 8
-    const int s_row = tid >> 3;       // + 32 j
-    const int s_col = (tid & 7) * 4;  // float offset inside the chunk
-    const float* xrow[4];
+    // staging assignment: float4 #f = tid + 256 j  ->  row f / F4_PER_ROW, 16-byte column f % F4_PER_ROW
+    const int s_row = tid / C::F4_PER_ROW;             // + ROWS_PER_PASS * j
+    const int s_col = (tid % C::F4_PER_ROW) * 4;       // float offset inside the chunk
+    const float* xrow[C::XV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int t = tok_base + s_row + 32 * j;
+    for (int j = 0; j < C::XV; ++j) {
+        int t = tok_base + s_row + C::ROWS_PER_PASS * j;
         if (t > N - 1) t = N - 1;
         xrow[j] = x + static_cast<size_t>(t) * D + s_col;
     }
 
-    auto load_stage = [&](Stage& st, int ct, int kc) {
-        const int col = kc * BK + s_col;
+    auto load_stage = [&](Stage<C>& st, int ct, int kc) {
+        const int col = kc * BKC + s_col;
         const bool in = col < D;  // D % 4 == 0, so a float4 is wholly in or out
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = (tile_begin + ct) * CODE_TILE + s_row + 32 * j;
+        for (int j = 0; j < C::XV; ++j) st.xv[j] = in ? *reinterpret_cast<const f32x4*>(xrow[j] + kc * BKC) : z;
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j) {
+            int c = (tile_begin + ct) * CODE_TILE + s_row + C::ROWS_PER_PASS * j;
             if (c > K - 1) c = K - 1;
-            const float* wp = w + static_cast<size_t>(c) * D + s_col + kc * BK;
-            const float* xp = xrow[j] + kc * BK;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            st.xv[j] = in ? *reinterpret_cast<const f32x4*>(xp) : z;
+            const float* wp = w + static_cast<size_t>(c) * D + s_col + kc * BKC;
             st.wv[j] = in ? *reinterpret_cast<const f32x4*>(wp) : z;
         }
     };
-    auto store_stage = [&](const Stage& st, int buf) {
-        float* xs = lds + buf * (2 * LDS_IMG);
-        float* ws = xs + LDS_IMG;
+    auto store_stage = [&](const Stage<C>& st, int buf) {
+        float* xs = lds + buf * C::STAGE;
+        float* ws = xs + C::X_IMG;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int off = (s_row + 32 * j) * LDS_ROW + s_col;
-            *reinterpret_cast<f32x4*>(xs + off) = st.xv[j];
-            *reinterpret_cast<f32x4*>(ws + off) = st.wv[j];
-        }
+        for (int j = 0; j < C::XV; ++j)
+            *reinterpret_cast<f32x4*>(xs + (s_row + C::ROWS_PER_PASS * j) * ROW + s_col) = st.xv[j];
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j)
+            *reinterpret_cast<f32x4*>(ws + (s_row + C::ROWS_PER_PASS * j) * ROW + s_col) = st.wv[j];
     };
 
     // per-lane token data
@@ -206,48 +231,78 @@ __global__ __launch_bounds__(256, 2) void dist_mfma_kernel(
     float best = __int_as_float(0x7F800000);
     int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;  // local code id (before code_offset)
 
-    Stage st;
+    Stage<C> st;
     load_stage(st, 0, 0);
     store_stage(st, 0);
     __syncthreads();
 
     int it = 0;
     for (int ct = 0; ct < n_tiles; ++ct) {
-        f32x16 acc[4];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
         for (int kc = 0; kc < n_chunks; ++kc, ++it) {
             const bool has_next = it + 1 < total;
-            if (has_next) {
-                int nkc = kc + 1, nct = ct;
-                if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
-                load_stage(st, nct, nkc);
-            }
-            const float* xs = lds + (it & 1) * (2 * LDS_IMG) + (wave * 32 + l31) * LDS_ROW + 4 * h;
-            const float* ws = lds + (it & 1) * (2 * LDS_IMG) + LDS_IMG + l31 * LDS_ROW + 4 * h;
+            const float* xs = lds + (it & 1) * C::STAGE + (wave * 32 + l31) * ROW + 4 * h;
+            const float* ws = lds + (it & 1) * C::STAGE + C::X_IMG + l31 * ROW + 4 * h;
+            auto read_frag = [&](Frag<C>& f, int g) {
+                f.b = *reinterpret_cast<const f32x4*>(xs + 8 * g);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(xs + 8 * g);
-                f32x4 a[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f32x4*>(ws + t * 32 * LDS_ROW + 8 * g);
+                for (int t = 0; t < NT; ++t) f.a[t] = *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + 8 * g);
+            };
+            auto mma = [&](const Frag<C>& f) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[j], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][j], f.b[j], acc[t], 0, 0, 0);
+            };
+            if (C::PF) {
+                Frag<C> f0, f1;
+                read_frag(f0, 0);
+                if (has_next) {
+                    int nkc = kc + 1, nct = ct;
+                    if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
+                    load_stage(st, nct, nkc);
+                }
+#pragma unroll
+                for (int g = 0; g < C::G; g += 2) {
+                    if (g + 1 < C::G) read_frag(f1, g + 1);
+                    mma(f0);
+                    if (g + 2 < C::G) read_frag(f0, g + 2);
+                    if (g + 1 < C::G) mma(f1);
+                }
+            } else {
+                if (has_next && C::ABL < 1) {
+                    int nkc = kc + 1, nct = ct;
+                    if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
+                    load_stage(st, nct, nkc);
+                }
+                if (C::ABL >= 3) {
+                    Frag<C> f;
+                    read_frag(f, 0);
+#pragma unroll
+                    for (int g = 0; g < C::G; ++g) mma(f);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < C::G; ++g) {
+                        Frag<C> f;
+                        read_frag(f, g);
+                        mma(f);
+                    }
+                }
             }
-            if (has_next) store_stage(st, (it + 1) & 1);
-            __syncthreads();
+            if (has_next && C::ABL < 1) store_stage(st, (it + 1) & 1);
+            if (C::ABL < 2) __syncthreads();
         }
 
         // epilogue for this code tile: d = fl(fl(xx + ee) - 2 dot), running first-minimum per token
         const int code0 = (tile_begin + ct) * CODE_TILE + 4 * h;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int cb = code0 + t * 32 + 8 * g4;
@@ -695,6 +750,107 @@ int pick_nch(int64_t D) {
     return 0;
 }
 
+int g_dist_variant = 0;  // tuning knob (t5vq_set_tuning); 0 = default configuration
+
+using CfgDefault = DistCfg<4, 32, false, 2>;
+#ifdef T5VQ_TUNING
+using Cfg1 = DistCfg<4, 32, true, 2>;
+using Cfg2 = DistCfg<8, 16, false, 2>;
+using Cfg3 = DistCfg<8, 16, true, 2>;
+using Cfg4 = DistCfg<4, 16, true, 3>;
+using Cfg5 = DistCfg<8, 32, true, 1>;
+using Cfg6 = DistCfg<4, 16, false, 3>;
+using Cfg7 = DistCfg<8, 32, false, 1>;
+using Cfg8 = DistCfg<4, 32, false, 2, 1>;
+using Cfg9 = DistCfg<4, 32, false, 2, 2>;
+using Cfg10 = DistCfg<4, 32, false, 2, 3>;
+using Cfg11 = DistCfg<8, 32, false, 1, 1>;
+using Cfg12 = DistCfg<8, 32, false, 1, 2>;
+using Cfg13 = DistCfg<8, 32, false, 1, 3>;
+#endif
+
+template <class C>
+int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
+                           int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
+                           float* dist, hipStream_t stream) {
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    T5VQ_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, true, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_done[dev] = true;
+    }
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
+    // Split the codebook over workgroups when token tiles alone cannot fill 256 CUs x 2 workgroups.
+    int64_t splits = 1;
+    if (!dist) {
+        while (tok_tiles * splits < 512 && splits * 2 <= code_tiles && splits < 64) splits *= 2;
+    }
+    const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
+    const int atomic = (splits > 1 || merge) ? 1 : 0;
+    if (!dist && splits > 1 && !merge) {
+        hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<long long*>(keys), static_cast<long long>(N));
+        T5VQ_CHECK_HIP(hipGetLastError());
+    }
+    const dim3 grid(static_cast<unsigned>(tok_tiles * splits));
+    const long long* rg = reinterpret_cast<const long long*>(range);
+    long long* kp = reinterpret_cast<long long*>(keys);
+#define T5VQ_DIST_ARGS                                                                                        \
+    x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
+        static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
+    if (dist) {
+        hipLaunchKernelGGL((dist_mfma_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, 0, kp, dist);
+    } else if (range) {
+        hipLaunchKernelGGL((dist_mfma_kernel<C, true, false>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp, dist);
+    } else {
+        hipLaunchKernelGGL((dist_mfma_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp, dist);
+    }
+#undef T5VQ_DIST_ARGS
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int launch_dist(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
+                       int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys, float* dist,
+                       hipStream_t stream) {
+    T5VQ_REQUIRE(x && w && xx && ee, "null input");
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
+    T5VQ_REQUIRE(aligned16(x) && aligned16(w) && aligned16(ee), "x, w, ee must be 16-byte aligned");
+    T5VQ_REQUIRE(N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 256, "N or K too large");
+    T5VQ_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
+#define T5VQ_GO(CFG) return launch_dist_cfg<CFG>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream)
+    switch (g_dist_variant) {
+#ifdef T5VQ_TUNING
+        case 1: T5VQ_GO(Cfg1);
+        case 2: T5VQ_GO(Cfg2);
+        case 3: T5VQ_GO(Cfg3);
+        case 4: T5VQ_GO(Cfg4);
+        case 5: T5VQ_GO(Cfg5);
+        case 6: T5VQ_GO(Cfg6);
+        case 7: T5VQ_GO(Cfg7);
+        case 8: T5VQ_GO(Cfg8);
+        case 9: T5VQ_GO(Cfg9);
+        case 10: T5VQ_GO(Cfg10);
+        case 11: T5VQ_GO(Cfg11);
+        case 12: T5VQ_GO(Cfg12);
+        case 13: T5VQ_GO(Cfg13);
+#endif
+        default: T5VQ_GO(CfgDefault);
+    }
+#undef T5VQ_GO
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -703,6 +859,10 @@ int pick_nch(int64_t D) {
 extern "C" {
 
 int t5vq_version(void) { return 100; }
+int t5vq_set_tuning(int variant) {
+    g_dist_variant = variant;
+    return T5VQ_OK;
+}
 const char* t5vq_last_error(void) { return g_err; }
 int64_t t5vq_padded_codes(int64_t K) { return (K + T5VQ_CODE_PAD - 1) / T5VQ_CODE_PAD * T5VQ_CODE_PAD; }
 int64_t t5vq_gather_blocks(int64_t N) { return (N + GS_TOK - 1) / GS_TOK; }
@@ -719,64 +879,6 @@ int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, i
     T5VQ_REQUIRE(bx + bw < (1LL << 31), "too many rows");
     hipLaunchKernelGGL(row_sqnorms_kernel, dim3(static_cast<unsigned>(bx + bw)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, N, xx, w, K, kpad, ee, static_cast<int>(D), bx);
-    T5VQ_CHECK_HIP(hipGetLastError());
-    return T5VQ_OK;
-}
-
-static int launch_dist(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
-                       int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys, float* dist,
-                       hipStream_t stream) {
-    T5VQ_REQUIRE(x && w && xx && ee, "null input");
-    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
-    T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
-    T5VQ_REQUIRE(aligned16(x) && aligned16(w) && aligned16(ee), "x, w, ee must be 16-byte aligned");
-    T5VQ_REQUIRE(N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - CODE_TILE, "N or K too large");
-    T5VQ_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
-
-    static bool attr_done[64] = {false};
-    int dev = 0;
-    T5VQ_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<false, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
-        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<true, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
-        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<false, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DIST_LDS_BYTES));
-        attr_done[dev] = true;
-    }
-
-    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
-    const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
-    // Split the codebook over workgroups when token tiles alone cannot fill 256 CUs x 2 workgroups.
-    int64_t splits = 1;
-    if (!dist) {
-        while (tok_tiles * splits < 512 && splits * 2 <= code_tiles && splits < 64) splits *= 2;
-    }
-    const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
-    const int atomic = (splits > 1 || merge) ? 1 : 0;
-    if (!dist && splits > 1 && !merge) {
-        hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<long long*>(keys), static_cast<long long>(N));
-        T5VQ_CHECK_HIP(hipGetLastError());
-    }
-    const dim3 grid(static_cast<unsigned>(tok_tiles * splits));
-    const long long* rg = reinterpret_cast<const long long*>(range);
-    long long* kp = reinterpret_cast<long long*>(keys);
-    if (dist) {
-        hipLaunchKernelGGL((dist_mfma_kernel<false, true>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee, rg,
-                           static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits),
-                           static_cast<int>(tiles_per_split), static_cast<long long>(code_offset), 0, kp, dist);
-    } else if (range) {
-        hipLaunchKernelGGL((dist_mfma_kernel<true, false>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee, rg,
-                           static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits),
-                           static_cast<int>(tiles_per_split), static_cast<long long>(code_offset), atomic, kp, dist);
-    } else {
-        hipLaunchKernelGGL((dist_mfma_kernel<false, false>), grid, dim3(256), DIST_LDS_BYTES, stream, x, w, xx, ee,
-                           rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D),
-                           static_cast<int>(splits), static_cast<int>(tiles_per_split),
-                           static_cast<long long>(code_offset), atomic, kp, dist);
-    }
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }

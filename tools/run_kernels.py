@@ -1,0 +1,37 @@
+"""Small driver for profiler passes: a few launches of the hot kernels at a BASELINE shape.
+
+    python3 tools/run_kernels.py [c3|c1|c2|c4] [reps] [dist|step]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from t5vqvae_amd import VectorQuantizerEMA, ops  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+what = sys.argv[3] if len(sys.argv) > 3 else "step"
+dev = torch.device("cuda", 0)
+n, k, d, update, _ = bench.WORKLOADS[workload]
+w, ema_w, cs, x = bench.build_state(workload, "uniform", 0, 1, dev)
+if what == "dist":
+    flat = x.reshape(-1, d)
+    xx, ee = ops.row_sqnorms(flat, w)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    for _ in range(reps):
+        ops.dist_argmin(flat, w, xx, ee, keys=keys)
+else:
+    mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
+    with torch.no_grad():
+        mod._embedding.weight.copy_(w)
+        mod._ema_w.copy_(ema_w)
+        mod._ema_cluster_size.copy_(cs)
+        mod.encodings = "indices"
+        mod.train(update)
+        for _ in range(reps):
+            mod(x)
+torch.cuda.synchronize()
+print("done")
