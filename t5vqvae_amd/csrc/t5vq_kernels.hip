@@ -171,8 +171,12 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int split = blockIdx.x % n_splits;
-    const int tok_base = (blockIdx.x / n_splits) * TOK_TILE;
+    // Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness): the n_splits
+    // workgroups of one token tile are given ids 8 apart so that their X tile is fetched into ONE L2.
+    const int grp = blockIdx.x / (8 * n_splits);
+    const int split = (blockIdx.x / 8) % n_splits;
+    const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
+    if (tok_base >= N) return;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     const int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
@@ -348,6 +352,231 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
         if (best_code != CODE_NONE) {
             long long gi = code_offset + best_code;
             if (RANGED) gi -= r_start;  // slice-relative, as the reference returns it
+            key = pack_key(best, static_cast<int>(gi));
+        }
+        if (atomic_merge) {
+            if (key != KEY_NONE) atomicMin(keys + tok, key);
+        } else {
+            keys[tok] = key;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (v2): the same tile and arithmetic as dist_mfma_kernel, restructured so that ONE wave keeps the matrix
+// pipe fed by itself.  Measured on v1 (tools/tune_dist.py ablations, C3): 95 % of fp32 MFMA peak with the
+// staging removed, 83 % with it -- the global loads and ds_writes were clumped before / after the MFMAs of a
+// chunk, where the issuing wave starves the pipe.  Here the loop body is one basic block (no tail / has-next
+// branches: D % BKC == 0 is required, the last iteration reloads a valid chunk into the idle buffer), source
+// pointers are advanced instead of recomputed, LDS fragments are double-buffered in registers, and
+// sched_group_barrier pins the order: every global load, ds_read and ds_write is issued in the 64-cycle
+// shadow of an MFMA.
+// ------------------------------------------------------------------------------------------------
+#define T5VQ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+template <class C, bool RANGED>
+__global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
+    const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
+    int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE, G = C::G;
+    constexpr int NLD = C::XV + C::WV;
+    static_assert(G >= 2 && NLD + NT + 1 <= 4 * NT, "interleave plan needs room");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness): the n_splits
+    // workgroups of one token tile are given ids 8 apart so that their X tile is fetched into ONE L2.
+    const int grp = blockIdx.x / (8 * n_splits);
+    const int split = (blockIdx.x / 8) % n_splits;
+    const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
+    if (tok_base >= N) return;
+    const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > n_code_tiles) tile_end = n_code_tiles;
+    const int n_tiles = tile_end - tile_begin;
+    if (n_tiles <= 0) return;
+    const int n_chunks = D / BKC;
+
+    const int s_row = tid / C::F4_PER_ROW;
+    const int s_col = (tid % C::F4_PER_ROW) * 4;
+    // global address space stated explicitly: through a lambda parameter hipcc otherwise falls back to
+    // flat loads, which also count on lgkmcnt and stall the LDS fragment waits behind HBM latency
+    typedef const f32x4 __attribute__((address_space(1))) * gvec_t;
+    typedef const float __attribute__((address_space(1))) * gptr_t;
+    const gptr_t xg = (gptr_t)x;
+    const gptr_t wg = (gptr_t)w;
+    gptr_t xp[C::XV];
+#pragma unroll
+    for (int j = 0; j < C::XV; ++j) {
+        int t = tok_base + s_row + C::ROWS_PER_PASS * j;
+        if (t > N - 1) t = N - 1;
+        xp[j] = xg + static_cast<size_t>(t) * D + s_col;
+    }
+    gptr_t wpc[C::WV];
+    gptr_t wpn[C::WV];
+    auto set_wptrs = [&](gptr_t (&wp)[C::WV], int ct) {
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j) {
+            int c = (tile_begin + ct) * CODE_TILE + s_row + C::ROWS_PER_PASS * j;
+            if (c > K - 1) c = K - 1;
+            wp[j] = wg + static_cast<size_t>(c) * D + s_col;
+        }
+    };
+    const int st_off = s_row * ROW + s_col;   // + ROWS_PER_PASS * ROW * j
+
+    const int tok = tok_base + wave * 32 + l31;
+    const int tok_c = tok < N ? tok : N - 1;
+    const float xv = xx[tok_c];
+    long long r_start = 0, r_end = 0;
+    if (RANGED) {
+        r_start = range[2 * static_cast<size_t>(tok_c)];
+        r_end = range[2 * static_cast<size_t>(tok_c) + 1];
+    }
+    float best = __int_as_float(0x7F800000);
+    int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;
+
+    set_wptrs(wpc, 0);
+    {   // prologue: chunk 0 of tile 0 into buffer 0
+#pragma unroll
+        for (int j = 0; j < C::XV; ++j)
+            *reinterpret_cast<f32x4*>(lds + st_off + C::ROWS_PER_PASS * ROW * j) = *(gvec_t)(xp[j]);
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j)
+            *reinterpret_cast<f32x4*>(lds + C::X_IMG + st_off + C::ROWS_PER_PASS * ROW * j) =
+                *(gvec_t)(wpc[j]);
+    }
+    __syncthreads();
+
+    const int rd_x = (wave * 32 + l31) * ROW + 4 * h;
+    const int rd_w = C::X_IMG + l31 * ROW + 4 * h;
+    int buf = 0;
+    f32x16 acc[NT];
+
+    // One chunk: MFMAs on buffer `buf`, staging of the next chunk (source pointers wp, column koff) into buf^1.
+    auto body = [&](const gptr_t (&wp)[C::WV], int koff) {
+        const float* xs = lds + buf * C::STAGE + rd_x;
+        const float* ws = lds + buf * C::STAGE + rd_w;
+        float* dst = lds + (buf ^ 1) * C::STAGE + st_off;
+        Frag<C> f[2];
+        Stage<C> st;
+        auto read_frag = [&](Frag<C>& fr, int g) {
+            fr.b = *reinterpret_cast<const f32x4*>(xs + 8 * g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fr.a[t] = *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + 8 * g);
+        };
+        read_frag(f[0], 0);
+#pragma unroll
+        for (int j = 0; j < C::XV; ++j) st.xv[j] = *(gvec_t)(xp[j] + koff);
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j) st.wv[j] = *(gvec_t)(wp[j] + koff);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) read_frag(f[(g + 1) & 1], g + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[g & 1].a[t][j], f[g & 1].b[j], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < C::XV; ++j)
+            *reinterpret_cast<f32x4*>(dst + C::ROWS_PER_PASS * ROW * j) = st.xv[j];
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j)
+            *reinterpret_cast<f32x4*>(dst + C::X_IMG + C::ROWS_PER_PASS * ROW * j) = st.wv[j];
+
+        // ---- issue order for the block above
+        T5VQ_SGB(SG_DS_RD, NT + 1);                       // fragments of k-group 0
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {                   // k-group 0: one global load per MFMA
+            T5VQ_SGB(SG_MFMA, 1);
+            T5VQ_SGB(SG_VMEM_RD, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < NT + 1; ++i) {                // ... then the fragments of k-group 1
+            T5VQ_SGB(SG_MFMA, 1);
+            T5VQ_SGB(SG_DS_RD, 1);
+        }
+        T5VQ_SGB(SG_MFMA, 4 * NT - NLD - (NT + 1));
+#pragma unroll
+        for (int g = 1; g + 1 < G; ++g) {                 // middle k-groups: next fragments behind the MFMAs
+#pragma unroll
+            for (int i = 0; i < NT + 1; ++i) {
+                T5VQ_SGB(SG_MFMA, 1);
+                T5VQ_SGB(SG_DS_RD, 1);
+            }
+            T5VQ_SGB(SG_MFMA, 4 * NT - (NT + 1));
+        }
+        T5VQ_SGB(SG_MFMA, 4 * NT - 2 * NLD > 0 ? 4 * NT - 2 * NLD : 0);   // last k-group: ds_writes at its end
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            T5VQ_SGB(SG_MFMA, (4 * NT - (4 * NT - 2 * NLD > 0 ? 4 * NT - 2 * NLD : 0)) / NLD);
+            T5VQ_SGB(SG_DS_WR, 1);
+        }
+        __syncthreads();
+        buf ^= 1;
+    };
+
+    for (int ct = 0; ct < n_tiles; ++ct) {
+        set_wptrs(wpn, ct + 1 < n_tiles ? ct + 1 : ct);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int kc = 1; kc < n_chunks; ++kc) body(wpc, kc * BKC);
+        body(wpn, 0);   // last chunk of the tile: stage chunk 0 of the next tile (a harmless reload on the last)
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j) wpc[j] = wpn[j];
+
+        const int code0 = (tile_begin + ct) * CODE_TILE + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cb = code0 + t * 32 + 8 * g4;
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(ee + cb);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int code = cb + c;
+                    const float s = xv + e4[c];
+                    const float d = fmaf(-2.0f, acc[t][g4 * 4 + c], s);
+                    if (RANGED) {
+                        const long long gc = code_offset + code;
+                        const bool valid = gc >= r_start && gc < r_end && code < K;
+                        if (valid && (d < best || best_code == CODE_NONE)) {
+                            best = d;
+                            best_code = code;
+                        }
+                    } else {
+                        if (d < best) {
+                            best = d;
+                            best_code = code;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const float ob = __shfl_xor(best, 32);
+    const int oc = __shfl_xor(best_code, 32);
+    if (oc != CODE_NONE && (best_code == CODE_NONE || ob < best || (ob == best && oc < best_code))) {
+        best = ob;
+        best_code = oc;
+    }
+    if (h == 0 && tok < N) {
+        long long key = KEY_NONE;
+        if (best_code != CODE_NONE) {
+            long long gi = code_offset + best_code;
+            if (RANGED) gi -= r_start;
             key = pack_key(best, static_cast<int>(gi));
         }
         if (atomic_merge) {
@@ -751,6 +980,7 @@ int pick_nch(int64_t D) {
 }
 
 int g_dist_variant = 0;  // tuning knob (t5vq_set_tuning); 0 = default configuration
+int g_force_splits = 0;  // tuning knob: 0 = heuristic
 
 using CfgDefault = DistCfg<4, 32, false, 2>;
 #ifdef T5VQ_TUNING
@@ -769,7 +999,7 @@ using Cfg12 = DistCfg<8, 32, false, 1, 2>;
 using Cfg13 = DistCfg<8, 32, false, 1, 3>;
 #endif
 
-template <class C>
+template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
                            int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
                            float* dist, hipStream_t stream) {
@@ -783,14 +1013,59 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        if (V2) {
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        }
         attr_done[dev] = true;
     }
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
-    // Split the codebook over workgroups when token tiles alone cannot fill 256 CUs x 2 workgroups.
+    // Code splits.  The S workgroups of one token tile that cover different code ranges are given block ids 8
+    // apart, i.e. ONE XCD, and share the X tile in its 4 MiB L2 (at the price of one more pass over W per round
+    // of resident workgroups).  Two criteria, in this order:
+    //  1. time: 512 workgroups are resident (256 CUs x 2); a launch runs ceil(WGs / 512) rounds of t code tiles
+    //     each (+ ~0.1 tile of prologue/epilogue per workgroup) -- pick t = tiles per split with the fewest
+    //     tile-times (fills the chip at small N, avoids a nearly empty last round);
+    //  2. among choices within 2 % of that, the fewest modelled L2-miss bytes (64 resident workgroups per XCD,
+    //     ~2.5 MB of L2 left for X tiles).  Measured at C3 (rocprofv3 FETCH_SIZE x 2): 12.9 GB unsplit ->
+    //     4.7 GB at 8 splits, kernel time -1 %.
     int64_t splits = 1;
     if (!dist) {
-        while (tok_tiles * splits < 512 && splits * 2 <= code_tiles && splits < 64) splits *= 2;
+        double best_time = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            double best_bytes = 0.0;
+            bool have = false;
+            for (int64_t t = 1; t <= code_tiles; ++t) {
+                const int64_t s = (code_tiles + t - 1) / t;
+                if (s > 256 || (t > 1 && (code_tiles + t - 2) / (t - 1) == s)) continue;  // same s, fewer tiles
+                const double rounds = static_cast<double>((tok_tiles * s + 511) / 512);
+                const double time = rounds * (static_cast<double>(t) + 0.1);
+                if (pass == 0) {
+                    if (best_time == 0.0 || time < best_time) best_time = time;
+                    continue;
+                }
+                if (time > best_time * 1.02) continue;
+                const double tiles_per_xcd = s >= 64 ? 1.0 : 64.0 / static_cast<double>(s);
+                const double x_ws = tiles_per_xcd * TOK_TILE * static_cast<double>(D) * 4.0;
+                const double miss = x_ws > 2.5e6 ? 1.0 - 2.5e6 / x_ws : 0.0;
+                const double x_bytes = static_cast<double>(N) * D * 4.0 * (1.0 + (static_cast<double>(t) - 1.0) * miss);
+                double w_rounds = static_cast<double>(tok_tiles) * s / 64.0;
+                if (w_rounds < 1.0) w_rounds = 1.0;
+                const double bytes = x_bytes + w_rounds * static_cast<double>(K) * D * 4.0;
+                if (!have || bytes < best_bytes) {
+                    have = true;
+                    best_bytes = bytes;
+                    splits = s;
+                }
+            }
+        }
+        if (g_force_splits > 0) {
+            splits = g_force_splits;
+            while (splits > code_tiles) splits /= 2;
+        }
     }
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int atomic = (splits > 1 || merge) ? 1 : 0;
@@ -799,13 +1074,20 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
                            reinterpret_cast<long long*>(keys), static_cast<long long>(N));
         T5VQ_CHECK_HIP(hipGetLastError());
     }
-    const dim3 grid(static_cast<unsigned>(tok_tiles * splits));
+    const dim3 grid(static_cast<unsigned>((tok_tiles + 7) / 8 * 8 * splits));
     const long long* rg = reinterpret_cast<const long long*>(range);
     long long* kp = reinterpret_cast<long long*>(keys);
 #define T5VQ_DIST_ARGS                                                                                        \
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
-    if (dist) {
+    const bool v2 = V2 && !dist && D % C::BKC == 0;
+    if (v2 && range) {
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, stream, T5VQ_DIST_ARGS,
+                           atomic, kp);
+    } else if (v2) {
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false>), grid, dim3(256), C::LDS_BYTES, stream, T5VQ_DIST_ARGS,
+                           atomic, kp);
+    } else if (dist) {
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, 0, kp, dist);
     } else if (range) {
@@ -830,6 +1112,8 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
     T5VQ_REQUIRE(N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 256, "N or K too large");
     T5VQ_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
 #define T5VQ_GO(CFG) return launch_dist_cfg<CFG>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream)
+#define T5VQ_GO2(CFG) \
+    return launch_dist_cfg<CFG, true>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream)
     switch (g_dist_variant) {
 #ifdef T5VQ_TUNING
         case 1: T5VQ_GO(Cfg1);
@@ -845,10 +1129,16 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
         case 11: T5VQ_GO(Cfg11);
         case 12: T5VQ_GO(Cfg12);
         case 13: T5VQ_GO(Cfg13);
+        case 20: T5VQ_GO2(CfgDefault);
+        case 21: T5VQ_GO2(Cfg2);
+        case 22: T5VQ_GO2(Cfg7);
+        case 23: T5VQ_GO2(Cfg6);
 #endif
-        default: T5VQ_GO(CfgDefault);
+        case 99: T5VQ_GO(CfgDefault);   // v1 main loop (reference point for tools/tune_dist.py)
+        default: T5VQ_GO2(CfgDefault);
     }
 #undef T5VQ_GO
+#undef T5VQ_GO2
 }
 
 }  // namespace
@@ -860,7 +1150,8 @@ extern "C" {
 
 int t5vq_version(void) { return 100; }
 int t5vq_set_tuning(int variant) {
-    g_dist_variant = variant;
+    g_force_splits = variant / 1000;
+    g_dist_variant = variant % 1000;
     return T5VQ_OK;
 }
 const char* t5vq_last_error(void) { return g_err; }

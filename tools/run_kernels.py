@@ -14,6 +14,8 @@ from t5vqvae_amd import VectorQuantizerEMA, ops  # noqa: E402
 workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 what = sys.argv[3] if len(sys.argv) > 3 else "step"
+from t5vqvae_amd import _lib  # noqa: E402
+_lib.load().t5vq_set_tuning(int(os.environ.get("T5VQ_TUNE", "0")))
 dev = torch.device("cuda", 0)
 n, k, d, update, _ = bench.WORKLOADS[workload]
 w, ema_w, cs, x = bench.build_state(workload, "uniform", 0, 1, dev)
