@@ -47,11 +47,12 @@ def build_state(workload, regime, rank, world, dev):
     return w, ema_w, cs, x
 
 
-def cpu_baseline(workload, budget_s=20.0):
-    """The oracle's faithful op-for-op path (dense one-hot, three matmuls) on the host cores, on a bounded
-    token slice of the same workload."""
+def cpu_baseline(workload, dev, budget_s=20.0):
+    """CPU leg: the oracle's faithful op-for-op path (dense one-hot, three matmuls) timed on
+    the host cores on a bounded token slice of the workload -- and, on the same slice and the same initial state,
+    used as the checker of one GPU step (the parity report SURVEY.md 8d asks for beside every benchmark)."""
     from oracle import vq_oracle as vo
-    from t5vqvae_amd import synth
+    from t5vqvae_amd import VectorQuantizerEMA, synth
     n, k, d, update, _ = WORKLOADS[workload]
     ns = min(n, 8192)
     w = synth.normal((k, d), 1000, 0)
@@ -65,14 +66,51 @@ def cpu_baseline(workload, budget_s=20.0):
         for i in range(6):
             st = st0.clone()
             t0 = time.perf_counter()
-            vo.faithful_forward(st, x, ema=True, training=update, commitment_cost=0.25)
+            ref = vo.faithful_forward(st, x, ema=True, training=update, commitment_cost=0.25)
             times.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start > budget_s and i >= 1:
                 break
-    med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+        # parity of one GPU step on the same slice / state
+        mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
+        mod._embedding.weight.copy_(st0.weight)
+        mod._ema_w.copy_(st0.ema_w)
+        mod._ema_cluster_size.copy_(st0.cluster_size)
+        mod.encodings = "indices"
+        mod.train(update)
+        loss, q, ppl, idx = mod(x.to(dev))
+        idx = idx.squeeze(1).cpu()
+        outside, inside = vo.classify_mismatches(x.view(-1, d), st0.weight, idx, ref.indices)
+        chk = vo.algorithmic_forward(st0.clone(), x, ema=True, training=update, commitment_cost=0.25, indices=idx)
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        return float((a - b).norm() / b.norm())
+    stc = st0.clone()
+    vo.algorithmic_forward(stc, x, ema=True, training=update, commitment_cost=0.25, indices=idx)
+    parity = {"tokens": ns, "idx_mismatch_outside_band": outside, "idx_mismatch_inside_band": inside,
+              "band": "|d64(a)-d64(b)| <= 1e-6*(|x|^2+max|e|^2)",
+              "rel_err": {"quantized": rel(q, chk.quantized), "loss": rel(loss, chk.loss),
+                          "perplexity": rel(ppl, chk.perplexity)}}
+    if update:
+        parity["rel_err"].update({"cluster_size": rel(mod._ema_cluster_size, stc.cluster_size),
+                                  "ema_w": rel(mod._ema_w.data, stc.ema_w),
+                                  "weight": rel(mod._embedding.weight.data, stc.weight)})
+    tt = times[1:] or times
+    med = sorted(tt)[len(tt) // 2]
     return {"value": ns / med, "unit": "vectors/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{ns}-token slice of the workload (K={k}, D={d}, fwd{'+EMA' if update else ''}), "
-                      f"median of {len(times[1:] or times)} calls, torch CPU fp32, {os.cpu_count()} host CPUs visible"}
+                      f"median of {len(tt)} calls, torch CPU fp32, {os.cpu_count()} host CPUs visible",
+            "parity": parity}
+
+
+def measured_traffic(workload):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json; counters cannot be read from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[workload]["dist_mfma_v2_kernel"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -160,17 +198,19 @@ def main():
             "config": {"workload": desc, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "D": d,
                        "regime": args.regime, "parallelism": f"token-sharded x{world}" if world > 1 else "single GPU",
                        "encodings": "indices (dense one-hot excluded, SURVEY 8b)"},
-            "roofline": {"bound": "mfma", "kernel": "dist_mfma_kernel (fused distance+argmin)",
+            "roofline": {"bound": "mfma", "kernel": "dist_mfma_v2_kernel (fused distance+argmin)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "kernel_ms": k_ms,
-                         "flops_per_launch": flops, "traffic": None},
+                         "flops_per_launch": flops, "traffic": measured_traffic(args.workload),
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+                         "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k},
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
         }
     if world > 1:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.workload)
+            result["cpu_baseline"] = cpu_baseline(args.workload, dev)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
