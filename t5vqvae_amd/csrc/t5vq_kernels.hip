@@ -398,11 +398,10 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
     if (tok_base >= N) return;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
-    const int tile_begin = split * tiles_per_split;
+    int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
-    const int n_tiles = tile_end - tile_begin;
-    if (n_tiles <= 0) return;
+    if (tile_end <= tile_begin) return;
     const int n_chunks = D / BKC;
 
     const int s_row = tid / C::F4_PER_ROW;
@@ -439,7 +438,33 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     if (RANGED) {
         r_start = range[2 * static_cast<size_t>(tok_c)];
         r_end = range[2 * static_cast<size_t>(tok_c) + 1];
+        // Only code tiles that intersect the union of this token tile's ranges are visited: with tokens
+        // bucketed by role (vqvae.py does that before the call) a grouped codebook costs
+        // 2 D sum_r N_r K_r flops instead of 2 D N K.
+        long long lo = r_start - code_offset, hi = r_end - code_offset;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > K ? K : hi;
+        int tlo = static_cast<int>(lo / CODE_TILE), thi = static_cast<int>((hi + CODE_TILE - 1) / CODE_TILE);
+        if (hi <= lo) { tlo = 0x7FFFFFFF; thi = 0; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tlo = min(tlo, __shfl_xor(tlo, o));
+            thi = max(thi, __shfl_xor(thi, o));
+        }
+        int* red = reinterpret_cast<int*>(lds);
+        if (lane == 0) { red[2 * wave] = tlo; red[2 * wave + 1] = thi; }
+        __syncthreads();
+        tlo = min(min(red[0], red[2]), min(red[4], red[6]));
+        thi = max(max(red[1], red[3]), max(red[5], red[7]));
+        __syncthreads();   // red is overwritten by the prologue below
+        tile_begin = max(tile_begin, tlo);
+        tile_end = min(tile_end, thi);
+        if (tile_end <= tile_begin) {   // workgroup-uniform: nothing admissible in this split
+            if (!atomic_merge && h == 0 && tok < N) keys[tok] = KEY_NONE;
+            return;
+        }
     }
+    const int n_tiles = tile_end - tile_begin;
     float best = __int_as_float(0x7F800000);
     int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;
 

@@ -108,9 +108,7 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         return full
 
     def _global_keys(self, x, w_local, ranges):
-        ops = vqvae.ops
-        xx, ee = ops.row_sqnorms(x, w_local)
-        keys = ops.dist_argmin(x, w_local, xx, ee, ranges, code_offset=self.code_begin)
+        keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin)
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return keys
 

@@ -100,6 +100,25 @@ class _QuantizerBase(nn.Module):
         if self.loss not in ops.LOSS_KINDS:
             exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
 
+    bucket_roles = True          # disentangled mode: visit tokens role by role (see _nearest_keys)
+
+    def _nearest_keys(self, x, w, ranges, code_offset=0):
+        """Packed (distance, index) keys of the nearest admissible codeword per token.
+
+        Disentangled mode with many tokens: tokens are first bucketed by their [start, end) range (a stable
+        argsort of N int64 and one row permutation -- data movement only), so that each 128-token tile of the
+        distance kernel carries (mostly) one role and skips every code tile outside it: a grouped codebook then
+        costs 2 D sum_r N_r K_r flops instead of 2 D N K.  Keys are scattered back to token order."""
+        if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
+            xx, ee = ops.row_sqnorms(x, w)
+            return ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
+        order = torch.argsort(ranges[:, 0] * (1 << 32) + ranges[:, 1], stable=True)
+        xs = x.index_select(0, order)
+        rs = ranges.index_select(0, order)
+        xx, ee = ops.row_sqnorms(xs, w)
+        ks = ops.dist_argmin(xs, w, xx, ee, rs, code_offset=code_offset)
+        return torch.empty_like(ks).index_copy_(0, order, ks)
+
     def _launch(self, x, w, ranges, plan, want_diff, want_q):
         """Order the kernels of one call (single GPU, or token-sharded when ``plan.group`` is set)."""
         n, d = x.shape
@@ -108,8 +127,7 @@ class _QuantizerBase(nn.Module):
         update = plan.ema and plan.training
         mse = plan.loss == "mse"
 
-        xx, ee = ops.row_sqnorms(x, w)
-        keys = ops.dist_argmin(x, w, xx, ee, ranges)
+        keys = self._nearest_keys(x, w, ranges)
 
         # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
         # token-sharded run all-reduces in ONE collective (sharded.py)
@@ -180,8 +198,7 @@ class _QuantizerBase(nn.Module):
     def _keys(self, inputs, srl):
         flat, ranges = self._flatten(inputs, srl)
         w = self._embedding.weight.detach()
-        xx, ee = ops.row_sqnorms(flat, w)
-        return flat, w, ops.dist_argmin(flat, w, xx, ee, ranges)
+        return flat, w, self._nearest_keys(flat, w, ranges)
 
     @torch.no_grad()
     def get_indices(self, inputs, srl=None):

@@ -83,6 +83,26 @@ def test_disentangled_straddling_ranges():
         check_step(m, st, x, srl, disent=True)
 
 
+def test_disentangled_bucketed_equals_unbucketed_and_oracle():
+    """N >= 1024 takes the role-bucketed route (token permutation + code-tile skipping)."""
+    k, d, n = 2048, 768, 3000
+    roles = [(0, 256), (256, 512), (512, 1024), (1024, 1100), (1100, 2048), (100, 1500)]
+    x = synth.normal((1, n, d), 16, 0)
+    srl = synth.role_ranges(n, roles, 16, 41).view(1, n, 2)
+    m, st = make_ema(k, d, 15, disentanglement=True)
+    m.eval()
+    m.bucket_roles = False
+    a = m(x.cuda(), srl.cuda())
+    m.bucket_roles = True
+    b = m(x.cuda(), srl.cuda())
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    assert torch.equal(m.get_indices(x.cuda(), srl.cuda()), b[3])
+    for t in range(2):
+        xt = synth.normal((1, n, d), 17, t)
+        srl_t = synth.role_ranges(n, roles, 17, 40 + t).view(1, n, 2)
+        check_step(m, st, xt, srl_t, disent=True)
+
+
 def test_cosine_loss_vs_oracle():
     m, st = make_ema(512, 768, 9, loss="cosine")
     check_step(m, st, synth.normal((4, 26, 768), 10, 0), loss="cosine")
