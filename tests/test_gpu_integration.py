@@ -1,0 +1,103 @@
+"""Integration harness: the reference's training step around the VQ bottleneck with a
+stand-in T5 -- HF ``transformers`` T5 built from a local config with random weights (no hub access).
+
+Mirrors t5/load_t5.py:374-533 (encoder -> self.vqvae(encoding, srl_ids) -> decoder cross-attention -> CE) and
+train_t5.py:33-63,105-185 (loss = CE + recon_loss, backward, clip_grad_norm_, AdamW.step, checkpoint of
+model.state_dict()).  Checks autograd through the straight-through output, optimizer interaction with the
+in-place-updated EMA Parameters, and the state_dict round trip with the reference's key names.
+"""
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build_t5():
+    from transformers import T5Config, T5ForConditionalGeneration
+    cfg = T5Config(vocab_size=384, d_model=768, d_kv=64, d_ff=1024, num_layers=2, num_decoder_layers=2,
+                   num_heads=12, decoder_start_token_id=0, pad_token_id=0, dropout_rate=0.0)
+    torch.manual_seed(0)
+    return T5ForConditionalGeneration(cfg)
+
+
+class T5AE(torch.nn.Module):
+    """The t5_AE wiring of the reference (t5/load_t5.py:218-533), reduced to the VQ branch."""
+
+    def __init__(self, t5, vqvae):
+        super().__init__()
+        self.t5, self.vqvae = t5, vqvae
+
+    def forward(self, input_ids, label_ids, srl_ids=None):
+        encoding = self.t5.encoder(input_ids=input_ids).last_hidden_state          # t5/load_t5.py:399
+        recon_loss, encoding, perplexity, _ = self.vqvae(encoding, srl_ids)         # t5/load_t5.py:518
+        ce = self.t5(encoder_outputs=(encoding,), labels=label_ids).loss            # t5/load_t5.py:530
+        return ce, recon_loss, perplexity
+
+
+@pytest.mark.parametrize("variant", ["ema", "plain", "ema_roles"])
+def test_training_loop_and_checkpoint(variant):
+    from t5vqvae_amd import VectorQuantizer, VectorQuantizerEMA
+    k, d = 1000, 768
+    roles = {"V": (0, 300), "residual": (300, k)} if variant == "ema_roles" else {}
+    if variant == "plain":
+        vq = VectorQuantizer(k, d, 0.25, decay=0.99, loss="mse")                    # train_t5.py:322
+    else:
+        vq = VectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=bool(roles), loss="mse", **roles)
+    model = T5AE(build_t5(), vq).cuda()
+    model.train()
+    ema_ptrs = {n: p.data_ptr() for n, p in vq.state_dict().items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 384, (8, 26), generator=g).cuda()                        # batch 8, set_seq_size 26
+    srl = None
+    if roles:
+        pick = torch.randint(0, 2, (8, 26), generator=g)
+        table = torch.tensor([roles["V"], roles["residual"]])
+        srl = table[pick].cuda()
+    hist = []
+    for step in range(40):
+        ce, recon, ppl = model(ids, ids, srl)
+        loss = ce + recon                                                           # train_t5.py:56
+        loss.backward()                                                             # train_t5.py:61
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)                     # train_t5.py:164
+        opt.step()
+        opt.zero_grad()
+        hist.append((float(ce), float(recon), float(ppl)))
+        assert all(map(lambda v: v == v and abs(v) != float("inf"), hist[-1])), hist[-1]
+    assert hist[-1][0] < hist[0][0] * 0.8, f"cross-entropy did not go down: {hist[0]} -> {hist[-1]}"
+    if variant != "plain":
+        assert vq._embedding.weight.grad is None and vq._ema_w.grad is None         # EMA state never gets gradients
+        assert {n: p.data_ptr() for n, p in vq.state_dict().items()} == ema_ptrs    # updated in place
+
+    # checkpoint round trip (train_t5.py:172-183 saves model.state_dict(); t5/load_t5.py:200-208 loads it)
+    buf = io.BytesIO()
+    torch.save(model.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=True)
+    assert "vqvae._embedding.weight" in sd
+    if variant != "plain":
+        assert {"vqvae._ema_w", "vqvae._ema_cluster_size"} <= set(sd)
+    if variant == "plain":
+        vq2 = VectorQuantizer(k, d, 0.25, decay=0.99)
+    else:
+        vq2 = VectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=bool(roles), **roles)
+    model2 = T5AE(build_t5(), vq2).cuda()
+    missing = model2.load_state_dict(sd, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval(), model2.eval()
+    with torch.no_grad():
+        a, b = model(ids, ids, srl), model2(ids, ids, srl)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_mid_encoder_call_site_returns_pair():
+    """modeling_t5.py:847-856 calls vqvae(hidden_states, srl) inside the encoder and keeps [0] and [1] only."""
+    from t5vqvae_amd import VectorQuantizerEMA
+    vq = VectorQuantizerEMA(512, 768, 0.25, decay=0.99).cuda().train()
+    hidden = torch.randn(4, 26, 768, device="cuda", requires_grad=True)
+    recon_loss, hidden_q, _, _ = vq(hidden, None)
+    assert hidden_q.shape == hidden.shape and recon_loss.dim() == 0
+    (hidden_q.pow(2).mean() + recon_loss).backward()
+    assert hidden.grad is not None and torch.isfinite(hidden.grad).all()
