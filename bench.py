@@ -132,8 +132,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # T5VQ_BENCH_FORCE_DIST=1 takes the RCCL path even at world size 1 (rehearsal on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("T5VQ_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from t5vqvae_amd import VectorQuantizerEMA, ops
     from t5vqvae_amd.sharded import shard_tokens
@@ -146,11 +150,11 @@ def main():
         mod._ema_cluster_size.copy_(cs)
     mod.encodings = "indices"
     mod.train(update)
-    if world > 1:
+    if use_dist:
         shard_tokens(mod)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +167,7 @@ def main():
             out = mod(x)
         barrier()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -206,7 +210,7 @@ def main():
                          "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k},
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
         }
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -214,7 +218,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "t5vq.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -375,7 +377,9 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
 #define T5VQ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
-template <class C, bool RANGED>
+// D2: staging registers are double-buffered too, so a chunk's global loads are issued TWO chunks ahead of its
+// use and have a whole chunk (~4k-8k cycles) to land before their ds_write (requires an even chunk count).
+template <class C, bool RANGED, bool D2>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
     const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
@@ -478,6 +482,13 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
             *reinterpret_cast<f32x4*>(lds + C::X_IMG + st_off + C::ROWS_PER_PASS * ROW * j) =
                 *(gvec_t)(wpc[j]);
     }
+    Stage<C> stg[2];
+    if (D2) {   // chunk 1 of tile 0 waits in registers
+#pragma unroll
+        for (int j = 0; j < C::XV; ++j) stg[1].xv[j] = *(gvec_t)(xp[j] + BKC);
+#pragma unroll
+        for (int j = 0; j < C::WV; ++j) stg[1].wv[j] = *(gvec_t)(wpc[j] + BKC);
+    }
     __syncthreads();
 
     const int rd_x = (wave * 32 + l31) * ROW + 4 * h;
@@ -486,22 +497,33 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     f32x16 acc[NT];
 
     // One chunk: MFMAs on buffer `buf`, staging of the next chunk (source pointers wp, column koff) into buf^1.
-    auto body = [&](const gptr_t (&wp)[C::WV], int koff) {
+    // P = parity of the chunk (D2 only): loads go to stg[P], the ds_writes drain stg[P ^ 1].
+    auto body = [&](const gptr_t (&wp)[C::WV], int koff, auto parity) {
+        constexpr int P = decltype(parity)::value;
         const float* xs = lds + buf * C::STAGE + rd_x;
         const float* ws = lds + buf * C::STAGE + rd_w;
         float* dst = lds + (buf ^ 1) * C::STAGE + st_off;
         Frag<C> f[2];
-        Stage<C> st;
+        Stage<C> st_local;
+        Stage<C>& st = D2 ? stg[P] : st_local;          // filled by this chunk's loads
+        Stage<C>& sw = D2 ? stg[P ^ 1] : st_local;      // written to LDS by this chunk
         auto read_frag = [&](Frag<C>& fr, int g) {
             fr.b = *reinterpret_cast<const f32x4*>(xs + 8 * g);
 #pragma unroll
             for (int t = 0; t < NT; ++t) fr.a[t] = *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + 8 * g);
         };
         read_frag(f[0], 0);
+        if (C::ABL != 5) {
 #pragma unroll
-        for (int j = 0; j < C::XV; ++j) st.xv[j] = *(gvec_t)(xp[j] + koff);
+            for (int j = 0; j < C::XV; ++j) st.xv[j] = *(gvec_t)(xp[j] + koff);
 #pragma unroll
-        for (int j = 0; j < C::WV; ++j) st.wv[j] = *(gvec_t)(wp[j] + koff);
+            for (int j = 0; j < C::WV; ++j) st.wv[j] = *(gvec_t)(wp[j] + koff);
+        } else {   // timing-only ablation: no global loads
+#pragma unroll
+            for (int j = 0; j < C::XV; ++j) st.xv[j] = f[0].b;
+#pragma unroll
+            for (int j = 0; j < C::WV; ++j) st.wv[j] = f[0].a[0];
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g + 1 < G) read_frag(f[(g + 1) & 1], g + 1);
@@ -511,34 +533,43 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
                 for (int t = 0; t < NT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[g & 1].a[t][j], f[g & 1].b[j], acc[t], 0, 0, 0);
         }
+        if (C::ABL != 4) {
 #pragma unroll
-        for (int j = 0; j < C::XV; ++j)
-            *reinterpret_cast<f32x4*>(dst + C::ROWS_PER_PASS * ROW * j) = st.xv[j];
+            for (int j = 0; j < C::XV; ++j)
+                *reinterpret_cast<f32x4*>(dst + C::ROWS_PER_PASS * ROW * j) = sw.xv[j];
 #pragma unroll
-        for (int j = 0; j < C::WV; ++j)
-            *reinterpret_cast<f32x4*>(dst + C::X_IMG + C::ROWS_PER_PASS * ROW * j) = st.wv[j];
+            for (int j = 0; j < C::WV; ++j)
+                *reinterpret_cast<f32x4*>(dst + C::X_IMG + C::ROWS_PER_PASS * ROW * j) = sw.wv[j];
+        } else {   // timing-only ablation: no ds_writes, loads kept alive
+#pragma unroll
+            for (int j = 0; j < C::XV; ++j) asm volatile("" ::"v"(st.xv[j]));
+#pragma unroll
+            for (int j = 0; j < C::WV; ++j) asm volatile("" ::"v"(st.wv[j]));
+        }
 
         // ---- issue order for the block above
         T5VQ_SGB(SG_DS_RD, NT + 1);                       // fragments of k-group 0
+        {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {                   // k-group 0: one global load per MFMA
-            T5VQ_SGB(SG_MFMA, 1);
-            T5VQ_SGB(SG_VMEM_RD, 1);
-        }
+            for (int i = 0; i < NLD; ++i) {                   // k-group 0: one global load per MFMA
+                T5VQ_SGB(SG_MFMA, 1);
+                T5VQ_SGB(SG_VMEM_RD, 1);
+            }
 #pragma unroll
-        for (int i = 0; i < NT + 1; ++i) {                // ... then the fragments of k-group 1
-            T5VQ_SGB(SG_MFMA, 1);
-            T5VQ_SGB(SG_DS_RD, 1);
-        }
-        T5VQ_SGB(SG_MFMA, 4 * NT - NLD - (NT + 1));
-#pragma unroll
-        for (int g = 1; g + 1 < G; ++g) {                 // middle k-groups: next fragments behind the MFMAs
-#pragma unroll
-            for (int i = 0; i < NT + 1; ++i) {
+            for (int i = 0; i < NT + 1; ++i) {                // ... then the fragments of k-group 1
                 T5VQ_SGB(SG_MFMA, 1);
                 T5VQ_SGB(SG_DS_RD, 1);
             }
-            T5VQ_SGB(SG_MFMA, 4 * NT - (NT + 1));
+            T5VQ_SGB(SG_MFMA, 4 * NT - NLD - (NT + 1));
+#pragma unroll
+            for (int g = 1; g + 1 < G; ++g) {                 // middle k-groups: next fragments behind the MFMAs
+#pragma unroll
+                for (int i = 0; i < NT + 1; ++i) {
+                    T5VQ_SGB(SG_MFMA, 1);
+                    T5VQ_SGB(SG_DS_RD, 1);
+                }
+                T5VQ_SGB(SG_MFMA, 4 * NT - (NT + 1));
+            }
         }
         T5VQ_SGB(SG_MFMA, 4 * NT - 2 * NLD > 0 ? 4 * NT - 2 * NLD : 0);   // last k-group: ds_writes at its end
 #pragma unroll
@@ -556,8 +587,19 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        for (int kc = 1; kc < n_chunks; ++kc) body(wpc, kc * BKC);
-        body(wpn, 0);   // last chunk of the tile: stage chunk 0 of the next tile (a harmless reload on the last)
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        if (D2) {
+            for (int kc = 0; kc + 2 < n_chunks; kc += 2) {
+                body(wpc, (kc + 2) * BKC, P0());
+                body(wpc, (kc + 3) * BKC, P1());
+            }
+            body(wpn, 0, P0());     // last two chunks: stage chunks 0 and 1 of the next tile
+            body(wpn, BKC, P1());   // (harmless reloads on the last tile)
+        } else {
+            for (int kc = 1; kc < n_chunks; ++kc) body(wpc, kc * BKC, P0());
+            body(wpn, 0, P0());   // last chunk of the tile: stage chunk 0 of the next tile
+        }
 #pragma unroll
         for (int j = 0; j < C::WV; ++j) wpc[j] = wpn[j];
 
@@ -1006,6 +1048,7 @@ int pick_nch(int64_t D) {
 
 int g_dist_variant = 0;  // tuning knob (t5vq_set_tuning); 0 = default configuration
 int g_force_splits = 0;  // tuning knob: 0 = heuristic
+int g_depth2 = 1;        // tuning knob: staging registers double-buffered (loads two chunks ahead)
 
 using CfgDefault = DistCfg<4, 32, false, 2>;
 #ifdef T5VQ_TUNING
@@ -1022,6 +1065,8 @@ using Cfg10 = DistCfg<4, 32, false, 2, 3>;
 using Cfg11 = DistCfg<8, 32, false, 1, 1>;
 using Cfg12 = DistCfg<8, 32, false, 1, 2>;
 using Cfg13 = DistCfg<8, 32, false, 1, 3>;
+using Cfg14 = DistCfg<4, 32, false, 2, 4>;
+using Cfg15 = DistCfg<4, 32, false, 2, 5>;
 #endif
 
 template <class C, bool V2 = false>
@@ -1039,9 +1084,13 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         if (V2) {
-            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false>),
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, true>),
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, true, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+            T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, true, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         }
         attr_done[dev] = true;
@@ -1106,12 +1155,19 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
     const bool v2 = V2 && !dist && D % C::BKC == 0;
-    if (v2 && range) {
-        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, stream, T5VQ_DIST_ARGS,
-                           atomic, kp);
+    const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
+    if (v2 && range && d2) {
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp);
+    } else if (v2 && d2) {
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp);
+    } else if (v2 && range) {
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, false>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp);
     } else if (v2) {
-        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false>), grid, dim3(256), C::LDS_BYTES, stream, T5VQ_DIST_ARGS,
-                           atomic, kp);
+        hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp);
     } else if (dist) {
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, 0, kp, dist);
@@ -1155,6 +1211,8 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
         case 12: T5VQ_GO(Cfg12);
         case 13: T5VQ_GO(Cfg13);
         case 20: T5VQ_GO2(CfgDefault);
+        case 24: T5VQ_GO2(Cfg14);
+        case 25: T5VQ_GO2(Cfg15);
         case 21: T5VQ_GO2(Cfg2);
         case 22: T5VQ_GO2(Cfg7);
         case 23: T5VQ_GO2(Cfg6);
@@ -1175,6 +1233,8 @@ extern "C" {
 
 int t5vq_version(void) { return 100; }
 int t5vq_set_tuning(int variant) {
+    g_depth2 = variant >= 100000 ? 0 : 1;   // +100000: single staging register set
+    variant %= 100000;
     g_force_splits = variant / 1000;
     g_dist_variant = variant % 1000;
     return T5VQ_OK;

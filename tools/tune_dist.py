@@ -30,7 +30,7 @@ for v in variants:
     if ref is None:
         ref = keys.clone()
     else:
-        if v < 8:    # variants >= 8 are timing-only ablations with wrong results
+        if v % 1000 not in (8, 9, 10, 11, 12, 13, 24, 25):    # these are timing-only ablations with wrong results
             assert torch.equal(keys, ref), f"variant {v} changes the keys"
 reps = 3 if n * k > 2 ** 28 else 20
 for rnd in range(5):
