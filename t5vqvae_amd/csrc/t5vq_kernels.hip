@@ -379,6 +379,17 @@ constexpr int SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x2
 
 // D2: staging registers are double-buffered too, so a chunk's global loads are issued TWO chunks ahead of its
 // use and have a whole chunk (~4k-8k cycles) to land before their ds_write (requires an even chunk count).
+// R fragment reads spread over R0 MFMAs (sched_group_barrier needs literal counts: compile-time recursion)
+template <int I, int R0, int R>
+__device__ __forceinline__ void sgb_spread_reads() {
+    if constexpr (I < R0) {
+        T5VQ_SGB(SG_MFMA, 1);
+        constexpr int c = R * (I + 1) / R0 - R * I / R0;
+        if constexpr (c > 0) T5VQ_SGB(SG_DS_RD, c);
+        sgb_spread_reads<I + 1, R0, R>();
+    }
+}
+
 template <class C, bool RANGED, bool D2>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE, G = C::G;
     constexpr int NLD = C::XV + C::WV;
-    static_assert(G >= 2 && NLD + NT + 1 <= 4 * NT, "interleave plan needs room");
+    static_assert(G >= 2 && NLD < 4 * NT, "interleave plan needs room");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -547,34 +558,37 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
             for (int j = 0; j < C::WV; ++j) asm volatile("" ::"v"(st.wv[j]));
         }
 
-        // ---- issue order for the block above
-        T5VQ_SGB(SG_DS_RD, NT + 1);                       // fragments of k-group 0
-        {
+        // ---- issue order for the block above (M MFMAs and R fragment reads per k-group, NLD loads / writes)
+        constexpr int M = 4 * NT, R = NT + 1, R0 = M - NLD, Q = M / NLD;
+        T5VQ_SGB(SG_DS_RD, R);                            // fragments of k-group 0
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {                   // k-group 0: one global load per MFMA
-                T5VQ_SGB(SG_MFMA, 1);
-                T5VQ_SGB(SG_VMEM_RD, 1);
-            }
+        for (int i = 0; i < NLD; ++i) {                   // k-group 0: one global load per MFMA ...
+            T5VQ_SGB(SG_MFMA, 1);
+            T5VQ_SGB(SG_VMEM_RD, 1);
+        }
+        if constexpr (R <= R0) {                          // ... then the fragments of k-group 1
 #pragma unroll
-            for (int i = 0; i < NT + 1; ++i) {                // ... then the fragments of k-group 1
+            for (int i = 0; i < R; ++i) {
                 T5VQ_SGB(SG_MFMA, 1);
                 T5VQ_SGB(SG_DS_RD, 1);
             }
-            T5VQ_SGB(SG_MFMA, 4 * NT - NLD - (NT + 1));
-#pragma unroll
-            for (int g = 1; g + 1 < G; ++g) {                 // middle k-groups: next fragments behind the MFMAs
-#pragma unroll
-                for (int i = 0; i < NT + 1; ++i) {
-                    T5VQ_SGB(SG_MFMA, 1);
-                    T5VQ_SGB(SG_DS_RD, 1);
-                }
-                T5VQ_SGB(SG_MFMA, 4 * NT - (NT + 1));
-            }
+            if constexpr (R0 - R > 0) T5VQ_SGB(SG_MFMA, R0 - R);
+        } else {
+            sgb_spread_reads<0, R0, R>();
         }
-        T5VQ_SGB(SG_MFMA, 4 * NT - 2 * NLD > 0 ? 4 * NT - 2 * NLD : 0);   // last k-group: ds_writes at its end
+#pragma unroll
+        for (int g = 1; g + 1 < G; ++g) {                 // middle k-groups: next fragments behind the MFMAs
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                T5VQ_SGB(SG_MFMA, 1);
+                T5VQ_SGB(SG_DS_RD, 1);
+            }
+            T5VQ_SGB(SG_MFMA, M - R);
+        }
+        if (M - Q * NLD > 0) T5VQ_SGB(SG_MFMA, M - Q * NLD);   // last k-group: ds_writes at its end
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            T5VQ_SGB(SG_MFMA, (4 * NT - (4 * NT - 2 * NLD > 0 ? 4 * NT - 2 * NLD : 0)) / NLD);
+            T5VQ_SGB(SG_MFMA, Q);
             T5VQ_SGB(SG_DS_WR, 1);
         }
         __syncthreads();
@@ -1051,6 +1065,7 @@ int g_force_splits = 0;  // tuning knob: 0 = heuristic
 int g_depth2 = 1;        // tuning knob: staging registers double-buffered (loads two chunks ahead)
 
 using CfgDefault = DistCfg<4, 32, false, 2>;
+using CfgSmall = DistCfg<2, 32, false, 2>;   // 128 x 64 tile: twice the workgroups when the problem cannot fill the chip
 #ifdef T5VQ_TUNING
 using Cfg1 = DistCfg<4, 32, true, 2>;
 using Cfg2 = DistCfg<8, 16, false, 2>;
@@ -1068,6 +1083,53 @@ using Cfg13 = DistCfg<8, 32, false, 1, 3>;
 using Cfg14 = DistCfg<4, 32, false, 2, 4>;
 using Cfg15 = DistCfg<4, 32, false, 2, 5>;
 #endif
+
+// Code splits.  The S workgroups of one token tile that cover different code ranges are given block ids 8 apart,
+// i.e. ONE XCD, and share the X tile in its 4 MiB L2 (at the price of one more pass over W per round of
+// resident workgroups).  Two criteria, in this order:
+//  1. time: each of the 256 CUs has one matrix pipe per SIMD that its (up to two) resident workgroups share, so
+//     a launch takes about ceil(WGs / 256) x (t + 0.1) tile-times, t = code tiles per split (0.1: prologue and
+//     epilogue of a workgroup) -- fills the chip at small N, avoids a nearly empty last round;
+//  2. among choices within 2 % of the best time, the fewest modelled L2-miss bytes (64 resident workgroups per
+//     XCD, ~2.5 MB of L2 left for X tiles).  Measured at C3 (rocprofv3 FETCH_SIZE x 2): 12.9 GB unsplit ->
+//     4.7 GB at 8 splits, kernel time -1 %.
+// Returns the number of splits; *time_out = modelled time in units of one 128-code tile on one pipe.
+int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time_out) {
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + code_tile - 1) / code_tile;
+    const double tile_cost = code_tile / 128.0;
+    int64_t splits = 1;
+    double best_time = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double best_bytes = 0.0;
+        bool have = false;
+        for (int64_t t = 1; t <= code_tiles; ++t) {
+            const int64_t s = (code_tiles + t - 1) / t;
+            if (s > 256 || (t > 1 && (code_tiles + t - 2) / (t - 1) == s)) continue;  // same s with fewer tiles
+            const double rounds = static_cast<double>((tok_tiles * s + 255) / 256);
+            const double time = rounds * (static_cast<double>(t) + 0.1) * tile_cost;
+            if (pass == 0) {
+                if (best_time == 0.0 || time < best_time) best_time = time;
+                continue;
+            }
+            if (time > best_time * 1.02) continue;
+            const double tiles_per_xcd = s >= 64 ? 1.0 : 64.0 / static_cast<double>(s);
+            const double x_ws = tiles_per_xcd * TOK_TILE * static_cast<double>(D) * 4.0;
+            const double miss = x_ws > 2.5e6 ? 1.0 - 2.5e6 / x_ws : 0.0;
+            const double x_bytes = static_cast<double>(N) * D * 4.0 * (1.0 + (static_cast<double>(t) - 1.0) * miss);
+            double w_rounds = static_cast<double>(tok_tiles) * s / 64.0;
+            if (w_rounds < 1.0) w_rounds = 1.0;
+            const double bytes = x_bytes + w_rounds * static_cast<double>(K) * D * 4.0;
+            if (!have || bytes < best_bytes) {
+                have = true;
+                best_bytes = bytes;
+                splits = s;
+            }
+        }
+    }
+    if (time_out) *time_out = best_time;
+    return splits;
+}
 
 template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
@@ -1097,45 +1159,9 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     }
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
-    // Code splits.  The S workgroups of one token tile that cover different code ranges are given block ids 8
-    // apart, i.e. ONE XCD, and share the X tile in its 4 MiB L2 (at the price of one more pass over W per round
-    // of resident workgroups).  Two criteria, in this order:
-    //  1. time: 512 workgroups are resident (256 CUs x 2); a launch runs ceil(WGs / 512) rounds of t code tiles
-    //     each (+ ~0.1 tile of prologue/epilogue per workgroup) -- pick t = tiles per split with the fewest
-    //     tile-times (fills the chip at small N, avoids a nearly empty last round);
-    //  2. among choices within 2 % of that, the fewest modelled L2-miss bytes (64 resident workgroups per XCD,
-    //     ~2.5 MB of L2 left for X tiles).  Measured at C3 (rocprofv3 FETCH_SIZE x 2): 12.9 GB unsplit ->
-    //     4.7 GB at 8 splits, kernel time -1 %.
     int64_t splits = 1;
     if (!dist) {
-        double best_time = 0.0;
-        for (int pass = 0; pass < 2; ++pass) {
-            double best_bytes = 0.0;
-            bool have = false;
-            for (int64_t t = 1; t <= code_tiles; ++t) {
-                const int64_t s = (code_tiles + t - 1) / t;
-                if (s > 256 || (t > 1 && (code_tiles + t - 2) / (t - 1) == s)) continue;  // same s, fewer tiles
-                const double rounds = static_cast<double>((tok_tiles * s + 511) / 512);
-                const double time = rounds * (static_cast<double>(t) + 0.1);
-                if (pass == 0) {
-                    if (best_time == 0.0 || time < best_time) best_time = time;
-                    continue;
-                }
-                if (time > best_time * 1.02) continue;
-                const double tiles_per_xcd = s >= 64 ? 1.0 : 64.0 / static_cast<double>(s);
-                const double x_ws = tiles_per_xcd * TOK_TILE * static_cast<double>(D) * 4.0;
-                const double miss = x_ws > 2.5e6 ? 1.0 - 2.5e6 / x_ws : 0.0;
-                const double x_bytes = static_cast<double>(N) * D * 4.0 * (1.0 + (static_cast<double>(t) - 1.0) * miss);
-                double w_rounds = static_cast<double>(tok_tiles) * s / 64.0;
-                if (w_rounds < 1.0) w_rounds = 1.0;
-                const double bytes = x_bytes + w_rounds * static_cast<double>(K) * D * 4.0;
-                if (!have || bytes < best_bytes) {
-                    have = true;
-                    best_bytes = bytes;
-                    splits = s;
-                }
-            }
-        }
+        splits = plan_splits(N, K, D, C::CODE_TILE, nullptr);
         if (g_force_splits > 0) {
             splits = g_force_splits;
             while (splits > code_tiles) splits /= 2;
@@ -1218,7 +1244,13 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
         case 23: T5VQ_GO2(Cfg6);
 #endif
         case 99: T5VQ_GO(CfgDefault);   // v1 main loop (reference point for tools/tune_dist.py)
-        default: T5VQ_GO2(CfgDefault);
+        case 98: T5VQ_GO2(CfgDefault);  // 128-code tile regardless of the problem size
+        case 97: T5VQ_GO2(CfgSmall);
+        default:
+            // fewer than one 128 x 128 tile per CU: halve the code tile to double the workgroups (measured:
+            // C2 52 -> 33 us; at >= 256 tiles the 128-code tile wins again, e.g. C1 75 % vs 54 % of peak)
+            if (!dist && ((N + TOK_TILE - 1) / TOK_TILE) * ((K + 127) / 128) < 256) T5VQ_GO2(CfgSmall);
+            T5VQ_GO2(CfgDefault);
     }
 #undef T5VQ_GO
 #undef T5VQ_GO2
