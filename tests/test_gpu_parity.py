@@ -175,6 +175,42 @@ def test_full_size_properties_c3():
     assert torch.equal(q2[0][finite], x2[0][finite])
 
 
+def test_full_size_properties_c4_share():
+    """C4's per-GPU share (N = 2^20 / 8, K = 16384): exact codewords round-trip, histogram mass is conserved,
+    embed sums equal counts x codeword (all members of a code are identical rows)."""
+    n, k, d = 131072, 16384, 768
+    from t5vqvae_amd import ops
+    w = synth.normal((k, d), 91, 0, device="cuda")
+    c = synth.uniform_int(n, k, 92, device="cuda")
+    x = w.index_select(0, c)
+    xx, ee = ops.row_sqnorms(x, w)
+    keys = ops.dist_argmin(x, w, xx, ee)
+    assert torch.equal(ops.unpack_keys(keys)[0], c)
+    counts = torch.empty(k, device="cuda")
+    es = torch.empty(k, d, device="cuda")
+    q = torch.empty_like(x)
+    part = torch.empty(ops.gather_blocks(n), device="cuda")
+    ops.gather_stats(x, w, keys, q=q, counts=counts, embed_sum=es, loss_partial=part)
+    assert torch.equal(q, x) and float(part.sum()) == 0.0
+    ref_counts = torch.bincount(c, minlength=k).float()
+    assert torch.equal(counts, ref_counts) and float(counts.sum()) == n
+    assert rel(es, w * ref_counts.unsqueeze(1)) <= 1e-6
+
+
+def test_rejects_unsupported_inputs():
+    from t5vqvae_amd import VectorQuantizerEMA
+    m = VectorQuantizerEMA(64, 6, 0.25, decay=0.99).cuda()           # D % 4 != 0
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        m(torch.zeros(2, 3, 6, device="cuda"))
+    m = VectorQuantizerEMA(64, 8, 0.25, decay=0.99).cuda()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 8, device="cuda", dtype=torch.float64))   # the reference path is fp32
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(0, 3, 8, device="cuda"))                        # empty batch: nothing to quantise
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 8, device="cuda").transpose(0, 2))        # not viewable as [-1, D] (vqvae.py:103)
+
+
 def test_methods_and_encodings_modes():
     m, st = make_ema(512, 768, 41)
     x = synth.normal((1, 45, 768), 42, 0)

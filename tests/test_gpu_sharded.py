@@ -44,6 +44,34 @@ def test_shard_merge_equals_unsharded_keys(ranged):
     assert torch.equal(keys, full)
 
 
+def test_c5_full_size_shards_equal_unsharded():
+    """BASELINE config 5 at full size on one GPU: K = 65536 as 8 shards of 8192 codes processed one after another
+    (code_offset + merge) must give the keys of the unsharded call bit for bit -- global argmin and the grouped
+    (8 role ranges aligned to the shards, and 5 unequal ranges that straddle them) forms."""
+    from t5vqvae_amd import ops
+    n, k, d, g = 65536, 65536, 768, 8
+    x = synth.normal((n, d), 81, 0, device="cuda")
+    w = synth.normal((k, d), 81, 1, device="cuda")
+    xx, ee = ops.row_sqnorms(x, w)
+    aligned = [(i * 8192, (i + 1) * 8192) for i in range(8)]
+    straddle = [(0, 20000), (20000, 20001), (20001, 40000), (40000, 65536), (8000, 60000)]
+    for roles in (None, aligned, straddle):
+        rg = synth.role_ranges(n, roles, 82, device="cuda") if roles else None
+        full = ops.dist_argmin(x, w, xx, ee, rg)
+        keys = None
+        for s in range(g):
+            ws = w[s * (k // g):(s + 1) * (k // g)]
+            _, ees = ops.row_sqnorms(None, ws)
+            keys = ops.dist_argmin(x, ws, xx, ees, rg, code_offset=s * (k // g), keys=keys, merge=s > 0)
+        assert torch.equal(keys, full)
+        idx = ops.unpack_keys(full)[0]
+        if roles:
+            width = (rg[:, 1] - rg[:, 0])
+            assert bool(((idx >= 0) & (idx < width)).all())        # slice-relative, inside the role's width
+        else:
+            assert bool(((idx >= 0) & (idx < k)).all())
+
+
 def test_stats_slice_and_two_phase_cluster_update():
     from t5vqvae_amd import ops
     n, k, d = 5000, 1024, 768
