@@ -153,6 +153,31 @@ int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out,
  * reference discards it. */
 int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream);
 
+/* ---- Composite calls: what a replacement of the module's forward must export ------------------
+ * They chain the entry points above on `stream`; results are bit-identical to calling them one by one.
+ *
+ * t5vq_vq_forward_f32 = vqvae/vqvae.py:103-128,147-152,160 (plain variant :24-64,71) plus the EMA statistics
+ * of :133,:141 in one host call: row norms -> distance + argmin -> gather / straight-through / loss terms /
+ * counts / embed_sum -> loss_sum[0] = sum of the loss terms.  `workspace` holds the per-call temporaries
+ * (keys, |x|^2, |e|^2, loss partials): t5vq_forward_workspace_bytes(N, K) bytes, 16-byte aligned, caller-owned.
+ * range, out_ste, out_q, out_diff, idx_out, counts, embed_sum, loss_sum are nullable as in
+ * t5vq_dist_argmin_f32 / t5vq_gather_stats_f32.  Whole-codebook form (code_offset 0, statistics for [0,K));
+ * a code-sharded caller uses the fine-grained calls. */
+int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K);
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
+                        int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                        t5vq_stream_t stream);
+
+/* t5vq_vq_ema_finalize_f32 = vqvae/vqvae.py:131-144 (if update != 0) and the loss / perplexity scalars
+ * (:148/:152,:157,:161-162): t5vq_ema_cluster_f32 (mode 1 or 0) followed by t5vq_ema_embed_f32.  A
+ * token-sharded caller all-reduces counts / embed_sum / loss_sum between the two composite calls. */
+int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
+                             const float* embed_sum, const float* loss_sum, int64_t K, int64_t D, int64_t n_tokens,
+                             float loss_denom, float decay, float one_minus_decay, float epsilon, float k_epsilon,
+                             float commitment_cost, int plain_variant, int update, float* scalars,
+                             t5vq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1462,4 +1462,61 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
     return T5VQ_OK;
 }
 
+// ---- composite entry points: the whole forward / the whole finalize behind ONE host call each -----------------
+namespace {
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+struct FwdWorkspace {
+    int64_t keys, xx, ee, partial, total;
+    FwdWorkspace(int64_t N, int64_t K) {
+        keys = 0;                                                   // int64 [N]
+        xx = align_up(8 * N, 16);                                   // fp32 [N]
+        ee = align_up(xx + 4 * N, 16);                              // fp32 [padded(K)], 16-byte aligned
+        partial = align_up(ee + 4 * t5vq_padded_codes(K), 16);      // fp32 [gather_blocks(N)]
+        total = align_up(partial + 4 * t5vq_gather_blocks(N), 256);
+    }
+};
+}  // namespace
+
+int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
+    if (N < 0 || K < 0) return 0;
+    return FwdWorkspace(N, K).total;
+}
+
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
+                        int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                        t5vq_stream_t stream) {
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    const FwdWorkspace ws(N, K);
+    T5VQ_REQUIRE(workspace && aligned16(workspace), "workspace null or not 16-byte aligned");
+    T5VQ_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
+    char* base = static_cast<char*>(workspace);
+    int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
+    float* xx = reinterpret_cast<float*>(base + ws.xx);
+    float* ee = reinterpret_cast<float*>(base + ws.ee);
+    float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
+    int rc = t5vq_row_sqnorms_f32(x, N, xx, w, K, ee, D, stream);
+    if (rc != T5VQ_OK) return rc;
+    rc = t5vq_dist_argmin_f32(x, w, xx, ee, range, N, K, D, 0, 0, keys, stream);
+    if (rc != T5VQ_OK) return rc;
+    rc = t5vq_gather_stats_f32(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts,
+                               embed_sum, partial, stream);
+    if (rc != T5VQ_OK) return rc;
+    if (loss_sum) rc = t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
+    return rc;
+}
+
+int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
+                             const float* embed_sum, const float* loss_sum, int64_t K, int64_t D, int64_t n_tokens,
+                             float loss_denom, float decay, float one_minus_decay, float epsilon, float k_epsilon,
+                             float commitment_cost, int plain_variant, int update, float* scalars,
+                             t5vq_stream_t stream) {
+    T5VQ_REQUIRE(!update || (cluster_size && ema_w && w && embed_sum), "update needs cluster_size, ema_w, w, embed_sum");
+    int rc = t5vq_ema_cluster_f32(update ? cluster_size : nullptr, counts, loss_sum, K, n_tokens, loss_denom, decay,
+                                  one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
+                                  update ? 1 : 0, scalars, stream);
+    if (rc != T5VQ_OK || !update) return rc;
+    return t5vq_ema_embed_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, stream);
+}
+
 }  // extern "C"

@@ -134,6 +134,65 @@ def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, 
                                              _p(embed_sum), _p(loss_partial), _stream(x)), "gather_stats")
 
 
+def forward_workspace_bytes(n: int, k: int) -> int:
+    return int(_lib.load().t5vq_forward_workspace_bytes(n, k))
+
+
+def vq_forward(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
+               loss_sum=None):
+    """The whole forward behind one host call (t5vq_vq_forward_f32): row norms, distance + argmin, gather /
+    straight-through / loss terms / EMA statistics, loss_sum.  Outputs are optional and caller-allocated."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d:
+        raise RuntimeError("vq_forward: x and w disagree on D")
+    if ranges is not None:
+        _need(ranges, "ranges", torch.int64, 2)
+        if tuple(ranges.shape) != (n, 2):
+            raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
+    for name, t, numel in (("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
+                           ("embed_sum", embed_sum, k * d), ("loss_sum", loss_sum, 1)):
+        if t is not None:
+            _need(t, name)
+            if t.numel() != numel:
+                raise RuntimeError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
+    if idx is not None:
+        _need(idx, "idx", torch.int64)
+        if idx.numel() != n:
+            raise RuntimeError(f"idx: expected {n} elements")
+    nbytes = forward_workspace_bytes(n, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
+                                           _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
+                                           _p(loss_sum), _stream(x)), "vq_forward")
+
+
+def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: int, loss_denom: float, decay: float,
+                 one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float,
+                 plain_variant: bool, update: bool, scalars):
+    """EMA update (if ``update``) + loss / perplexity scalars behind one host call (t5vq_vq_ema_finalize_f32)."""
+    lib = _lib.load()
+    _need(scalars, "scalars"), _need(counts, "counts")
+    k = counts.numel()
+    d = 0
+    if update:
+        _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum, "embed_sum"), _need(cluster_size, "cs")
+        d = w.shape[1]
+        if tuple(ema_w.shape) != (k, d) or tuple(w.shape) != (k, d) or embed_sum.numel() != k * d \
+                or cluster_size.numel() != k:
+            raise RuntimeError("ema_finalize: inconsistent shapes")
+    with torch.cuda.device(scalars.device):
+        _lib.check(lib.t5vq_vq_ema_finalize_f32(_p(cluster_size) if update else None, _p(ema_w) if update else None,
+                                                _p(w) if update else None, _p(counts),
+                                                _p(embed_sum) if update else None, _p(loss_sum), k, d, n_tokens,
+                                                loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                                                commitment_cost, 1 if plain_variant else 0, 1 if update else 0,
+                                                _p(scalars), _stream(scalars)), "ema_finalize")
+
+
 def reduce_partials(partials, out):
     lib = _lib.load()
     _need(partials, "partials"), _need(out, "out")

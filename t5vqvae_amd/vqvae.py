@@ -127,8 +127,6 @@ class _QuantizerBase(nn.Module):
         update = plan.ema and plan.training
         mse = plan.loss == "mse"
 
-        keys = self._nearest_keys(x, w, ranges)
-
         # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
         # token-sharded run all-reduces in ONE collective (sharded.py)
         kd = k * d if update else 0
@@ -136,14 +134,19 @@ class _QuantizerBase(nn.Module):
         embed_sum = stats[:kd].view(k, d) if update else None
         counts = stats[kd:kd + k]
         loss_sum = stats[kd + k:kd + k + 1]
-        partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
         ste = torch.empty_like(x)
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         diff = torch.empty_like(x) if want_diff else None
         q = torch.empty_like(x) if want_q else None
-        ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
-                         embed_sum=embed_sum, loss_partial=partial)
-        ops.reduce_partials(partial, loss_sum)
+        if ranges is not None and self.bucket_roles and n >= 1024:
+            keys = self._nearest_keys(x, w, ranges)              # role-bucketed: permute, search, scatter back
+            partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
+            ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+                             embed_sum=embed_sum, loss_partial=partial)
+            ops.reduce_partials(partial, loss_sum)
+        else:                                                    # the whole forward behind one host call
+            ops.vq_forward(x, w, ranges, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+                           embed_sum=embed_sum, loss_sum=loss_sum)
 
         n_total = n
         batch = plan.batch
@@ -156,13 +159,11 @@ class _QuantizerBase(nn.Module):
 
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
         denom = float(n_total * d) if mse else float(batch)
-        ops.ema_cluster(self._ema_cluster_size if update else None, counts, loss_sum, k, n_total, denom,
-                        plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema,
-                        1 if update else 0, scalars)
-        if update:
-            # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
-            ops.ema_embed(self._ema_w.data, self._embedding.weight.data, embed_sum, self._ema_cluster_size,
-                          plan.decay, 1 - plan.decay)
+        # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
+        ops.ema_finalize(self._ema_cluster_size if update else None, self._ema_w.data if update else None,
+                         self._embedding.weight.data if update else None, counts, embed_sum, loss_sum, n_total,
+                         denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema, update,
+                         scalars)
         return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q,
                 "dims": (n_total, d, k, batch)}
 

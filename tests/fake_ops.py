@@ -107,6 +107,25 @@ def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=Non
         loss_partial.copy_(pad.view(-1, 64).sum(1))
 
 
+def vq_forward(x, w, ranges, loss, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
+               loss_sum=None):
+    xx, ee = row_sqnorms(x, w)
+    keys = dist_argmin(x, w, xx, ee, ranges)
+    partial = torch.empty(gather_blocks(x.shape[0])) if loss_sum is not None else None
+    gather_stats(x, w, keys, loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts, embed_sum=embed_sum,
+                 loss_partial=partial)
+    if loss_sum is not None:
+        reduce_partials(partial, loss_sum)
+
+
+def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens, loss_denom, decay, one_minus_decay,
+                 epsilon, k_epsilon, commitment_cost, plain_variant, update, scalars):
+    ema_cluster(cluster_size if update else None, counts, loss_sum, counts.numel(), n_tokens, loss_denom, decay,
+                one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, 1 if update else 0, scalars)
+    if update:
+        ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay)
+
+
 def reduce_partials(partials, out):
     out[0] = partials.double().sum().float()
 

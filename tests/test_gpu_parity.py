@@ -265,3 +265,77 @@ def test_state_dict_round_trip_and_inplace_identity():
     x = synth.normal((1, 50, 768), 63, 0).cuda()
     m.eval(), m2.eval()
     assert torch.equal(m(x)[1], m2(x)[1])
+
+
+@pytest.mark.parametrize("n,k,d,ranged,loss", [(2880, 10000, 768, False, "mse"), (777, 130, 64, True, "mse"),
+                                               (4096, 512, 768, False, "cosine")])
+def test_composite_calls_equal_fine_grained(n, k, d, ranged, loss):
+    """t5vq_vq_forward_f32 / t5vq_vq_ema_finalize_f32 (one host call each) == the chain of fine-grained entry
+    points, bit for bit (atomics aside: embed_sum to 1e-6)."""
+    from t5vqvae_amd import ops
+    dev = "cuda"
+    w = synth.normal((k, d), 5, 0, device=dev)
+    x, _ = synth.clustered(n, w, 0.7, 6)
+    rg = synth.role_ranges(n, [(0, k // 3), (k // 3, k)], 7, 0, device=dev) if ranged else None
+
+    def bufs():
+        return dict(ste=torch.empty_like(x), diff=torch.empty_like(x), idx=torch.empty(n, dtype=torch.int64, device=dev),
+                    counts=torch.empty(k, device=dev), embed_sum=torch.empty(k, d, device=dev))
+    a, b = bufs(), bufs()
+    ls_a, ls_b = torch.empty(1, device=dev), torch.empty(1, device=dev)
+    ops.vq_forward(x, w, rg, loss, loss_sum=ls_a, **a)
+    xx, ee = ops.row_sqnorms(x, w)
+    keys = ops.dist_argmin(x, w, xx, ee, rg)
+    part = torch.empty(ops.gather_blocks(n), device=dev)
+    ops.gather_stats(x, w, keys, loss, loss_partial=part, **b)
+    ops.reduce_partials(part, ls_b)
+    for name in ("ste", "diff", "idx", "counts"):
+        assert torch.equal(a[name], b[name]), name
+    assert torch.equal(ls_a, ls_b)
+    assert rel(a["embed_sum"], b["embed_sum"]) < 1e-6
+
+    cs0 = torch.rand(k, device=dev) + 0.5
+    ew0 = synth.normal((k, d), 8, 0, device=dev)
+    args = (n, float(n * d), 0.99, 1 - 0.99, 1e-5, k * 1e-5, 0.25)
+    cs_a, ew_a, w_a, sc_a = cs0.clone(), ew0.clone(), w.clone(), torch.empty(4, device=dev)
+    ops.ema_finalize(cs_a, ew_a, w_a, b["counts"], b["embed_sum"], ls_b, *args, False, True, sc_a)
+    cs_b, ew_b, w_b, sc_b = cs0.clone(), ew0.clone(), w.clone(), torch.empty(4, device=dev)
+    ops.ema_cluster(cs_b, b["counts"], ls_b, k, *args, False, 1, sc_b)
+    ops.ema_embed(ew_b, w_b, b["embed_sum"], cs_b, 0.99, 1 - 0.99)
+    for u, v in ((cs_a, cs_b), (ew_a, ew_b), (w_a, w_b), (sc_a, sc_b)):
+        assert torch.equal(u, v)
+    # eval form: no update, buffers untouched
+    sc_e = torch.empty(4, device=dev)
+    ops.ema_finalize(None, None, None, b["counts"], None, ls_b, *args, False, False, sc_e)
+    assert torch.equal(sc_e[:2], sc_b[:2]) and float(sc_e[2]) == 0.0
+
+
+def test_module_step_replays_from_a_hip_graph():
+    """The C ABI only enqueues on the stream it is given and allocates nothing, so a whole training-mode call can be
+    captured once into a HIP graph and replayed: the replayed steps equal eager steps on a twin module."""
+    n, k, d = 2880, 1000, 768
+    m1, st = make_ema(k, d, 11)
+    m2, _ = make_ema(k, d, 11)
+    m1.encodings = m2.encodings = "indices"
+    x = synth.normal((n, d), 12, 0, device="cuda").view(64, 45, d)
+    xs = x.clone()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m1(xs)                                  # warm-up call outside the capture (first-launch set-up)
+        torch.cuda.current_stream().wait_stream(side)
+        m2(x)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m1(xs)
+        for step in range(3):
+            xs.copy_(x * (1.0 + 0.1 * step))
+            g.replay()
+            ref = m2(x * (1.0 + 0.1 * step))
+            torch.cuda.synchronize()
+            assert torch.equal(out[3], ref[3])
+            # embed_sum is accumulated with float atomics, so the two codebooks agree to rounding, not bitwise
+            assert rel(out[1], ref[1]) < 1e-6 and rel(out[0], ref[0]) < 1e-6 and rel(out[2], ref[2]) < 1e-6
+            assert rel(m1._embedding.weight.data, m2._embedding.weight.data) < 1e-6
+            assert rel(m1._ema_cluster_size, m2._ema_cluster_size) < 1e-7
