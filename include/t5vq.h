@@ -46,7 +46,8 @@ const char* t5vq_last_error(void);
 int t5vq_set_tuning(int variant);
 /* Length of the padded |e|^2 buffer for K codes: K rounded up to T5VQ_CODE_PAD. */
 int64_t t5vq_padded_codes(int64_t K);
-/* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens. */
+/* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens (a workgroup takes 64 tokens,
+ * or 16 when N < 32768 so that small batches still cover the CUs). */
 int64_t t5vq_gather_blocks(int64_t N);
 
 /* Row squared norms of two matrices in one launch.

@@ -75,12 +75,47 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ------------------------------------------------------------------------------------------------
 // K0: row squared norms (one wave per row, two matrices per launch)
 // ------------------------------------------------------------------------------------------------
+// Buffers a composite forward needs in a known state before its later kernels run; prepared by extra
+// workgroups of the row-norm launch instead of separate fill / memset launches.
+struct PrepArgs {
+    float* zero_a;       // counts
+    long long n_a;
+    float* zero_b;       // embed_sum
+    long long n_b;
+    long long* keys;     // filled with KEY_NONE (code splits merge into it with atomicMin)
+    long long n_keys;
+    int blocks;          // workgroups appended to the grid for this
+};
+
+__device__ __forceinline__ void zero_floats(float* p, long long n, long long gtid, long long gstride) {
+    if (!p || n <= 0) return;
+    long long head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2;  // floats up to 16-byte alignment
+    if (head > n) head = n;
+    const long long body4 = (n - head) >> 2;
+    f32x4* b = reinterpret_cast<f32x4*>(p + head);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = gtid; i < body4; i += gstride) b[i] = z;
+    if (gtid < head) p[gtid] = 0.f;
+    const long long tail0 = head + (body4 << 2);
+    if (gtid < n - tail0) p[tail0 + gtid] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void row_sqnorms_kernel(const float* __restrict__ x, long long n_x,
                                                           float* __restrict__ xx, const float* __restrict__ w,
                                                           long long n_w, long long n_w_pad, float* __restrict__ ee,
-                                                          int D, long long blocks_x) {
+                                                          int D, long long blocks_x, long long blocks_rows,
+                                                          PrepArgs prep) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (static_cast<long long>(blockIdx.x) >= blocks_rows) {  // preparation tail
+        const long long gtid = (static_cast<long long>(blockIdx.x) - blocks_rows) * 256 + threadIdx.x;
+        const long long gstride = static_cast<long long>(prep.blocks) * 256;
+        zero_floats(prep.zero_a, prep.n_a, gtid, gstride);
+        zero_floats(prep.zero_b, prep.n_b, gtid, gstride);
+        if (prep.keys)
+            for (long long i = gtid; i < prep.n_keys; i += gstride) prep.keys[i] = KEY_NONE;
+        return;
+    }
     const float* src;
     float* dst;
     long long row, n_rows, n_out;
@@ -690,28 +725,55 @@ __global__ void unpack_keys_kernel(const long long* __restrict__ keys, long long
 // global_atomic_add_f32 wave-instruction covers 256 contiguous bytes.
 // Lane layout inside a row: float4 #(j*64 + lane), j < NCH  (NCH = ceil(D / 256)).
 // ------------------------------------------------------------------------------------------------
-constexpr int GS_TOK = 64;
+constexpr int GS_TOK = 64;    // tokens per workgroup (large N)
+constexpr int GS_TOK_SMALL = 16;   // ... when N / 64 workgroups would leave most CUs idle
+constexpr int GS_SMALL_N = 32768;  // below this many tokens the small form is used (>= 2 workgroups per CU above)
+__host__ __device__ inline int gs_tok(long long N) { return N < GS_SMALL_N ? GS_TOK_SMALL : GS_TOK; }
 
-template <int NCH, bool COSINE>
+// Wave 0 of a workgroup: group the workgroup's TOK tokens by code.  Group g = (s_gcode[g], member mask
+// s_gmask[g]); groups are numbered by their first member.  counts (nullable) receives every group's size.
+// (Cutting a hot code's group into sub-groups for the four waves was measured and rejected: the extra flushes
+// contend on the same embed_sum row -- all tokens on one code: 113 -> 217 us at C3.)
+template <int TOK>
+__device__ __forceinline__ void build_groups(const int* s_code, unsigned long long* s_gmask, int* s_gcode,
+                                             int* s_ngroups, int lane, float* counts, int stats_begin,
+                                             int stats_count) {
+    const int mine = lane < TOK ? s_code[lane] : -1;
+    unsigned long long m = 0;
+    for (int t = 0; t < TOK; ++t)
+        if (s_code[t] == mine) m |= 1ull << t;
+    const bool leader = mine >= 0 && (__ffsll(static_cast<long long>(m)) - 1) == lane;
+    const unsigned long long lead_mask = __ballot(leader);
+    if (leader) {
+        const int slot = __popcll(lead_mask & ((1ull << lane) - 1ull));
+        s_gmask[slot] = m;
+        s_gcode[slot] = mine;
+        const int sc = mine - stats_begin;
+        if (counts && sc >= 0 && sc < stats_count) atomicAdd(counts + sc, static_cast<float>(__popcll(m)));
+    }
+    if (lane == 0) *s_ngroups = __popcll(lead_mask);
+}
+
+template <int NCH, bool COSINE, int TOK>
 __global__ __launch_bounds__(256) void gather_stats_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const long long* __restrict__ keys, int N, int K,
     int D, float* __restrict__ out_ste, float* __restrict__ out_q, float* __restrict__ out_diff,
     long long* __restrict__ idx_out, int stats_begin, int stats_count, float* __restrict__ counts,
     float* __restrict__ embed_sum, float* __restrict__ loss_partial) {
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // [4 waves][NCH*256] transposition rows
-    __shared__ int s_code[GS_TOK];
-    __shared__ unsigned long long s_gmask[GS_TOK];
-    __shared__ int s_gcode[GS_TOK];
+    __shared__ int s_code[TOK];
+    __shared__ unsigned long long s_gmask[TOK];
+    __shared__ int s_gcode[TOK];
     __shared__ int s_ngroups;
     __shared__ float s_red[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int tok0 = blockIdx.x * GS_TOK;
-    const int n_here = min(GS_TOK, N - tok0);
+    const int tok0 = blockIdx.x * TOK;
+    const int n_here = min(TOK, N - tok0);
 
-    if (tid < GS_TOK) {
+    if (tid < TOK) {
         int code = -1;
         if (tid < n_here) {
             code = key_index(keys[tok0 + tid]);
@@ -721,22 +783,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
         s_code[tid] = code;
     }
     __syncthreads();
-    if (wave == 0) {
-        const int mine = s_code[lane];
-        unsigned long long m = 0;
-        for (int t = 0; t < GS_TOK; ++t)
-            if (s_code[t] == mine) m |= 1ull << t;
-        const bool leader = mine >= 0 && (__ffsll(static_cast<long long>(m)) - 1) == lane;
-        const unsigned long long lead_mask = __ballot(leader);
-        if (leader) {
-            const int rank = __popcll(lead_mask & ((1ull << lane) - 1ull));
-            s_gmask[rank] = m;
-            s_gcode[rank] = mine;
-            const int sc = mine - stats_begin;
-            if (counts && sc >= 0 && sc < stats_count) atomicAdd(counts + sc, static_cast<float>(__popcll(m)));
-        }
-        if (lane == 0) s_ngroups = __popcll(lead_mask);
-    }
+    if (wave == 0) build_groups<TOK>(s_code, s_gmask, s_gcode, &s_ngroups, lane, counts, stats_begin, stats_count);
     __syncthreads();
     const int n_groups = s_ngroups;
 
@@ -962,20 +1009,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
         s_code[tid] = code;
     }
     __syncthreads();
-    if (wave == 0) {
-        const int mine = s_code[lane];
-        unsigned long long m = 0;
-        for (int t = 0; t < GS_TOK; ++t)
-            if (s_code[t] == mine) m |= 1ull << t;
-        const bool leader = mine >= 0 && (__ffsll(static_cast<long long>(m)) - 1) == lane;
-        const unsigned long long lead_mask = __ballot(leader);
-        if (leader) {
-            const int rank = __popcll(lead_mask & ((1ull << lane) - 1ull));
-            s_gmask[rank] = m;
-            s_gcode[rank] = mine;
-        }
-        if (lane == 0) s_ngroups = __popcll(lead_mask);
-    }
+    if (wave == 0) build_groups<GS_TOK>(s_code, s_gmask, s_gcode, &s_ngroups, lane, nullptr, 0, 0);
     __syncthreads();
     const int n_groups = s_ngroups;
     float* trow = tbuf + wave * (NCH * 256);
@@ -1131,6 +1165,8 @@ int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time
     return splits;
 }
 
+thread_local bool t_keys_prefilled = false;  // composite forward: keys already hold KEY_NONE
+
 template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
                            int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
@@ -1169,7 +1205,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     }
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int atomic = (splits > 1 || merge) ? 1 : 0;
-    if (!dist && splits > 1 && !merge) {
+    if (!dist && splits > 1 && !merge && !t_keys_prefilled) {
         hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<long long*>(keys), static_cast<long long>(N));
         T5VQ_CHECK_HIP(hipGetLastError());
@@ -1273,22 +1309,33 @@ int t5vq_set_tuning(int variant) {
 }
 const char* t5vq_last_error(void) { return g_err; }
 int64_t t5vq_padded_codes(int64_t K) { return (K + T5VQ_CODE_PAD - 1) / T5VQ_CODE_PAD * T5VQ_CODE_PAD; }
-int64_t t5vq_gather_blocks(int64_t N) { return (N + GS_TOK - 1) / GS_TOK; }
+int64_t t5vq_gather_blocks(int64_t N) { const int64_t t = gs_tok(N); return (N + t - 1) / t; }
 
-int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee, int64_t D,
-                         t5vq_stream_t stream) {
+static int launch_row_sqnorms(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee, int64_t D,
+                              PrepArgs prep, hipStream_t stream) {
     T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
     T5VQ_REQUIRE(N >= 0 && K >= 0, "negative row count");
     T5VQ_REQUIRE(N == 0 || (x && xx && aligned16(x)), "x/xx null or x not 16-byte aligned");
     T5VQ_REQUIRE(K == 0 || (w && ee && aligned16(w)), "w/ee null or w not 16-byte aligned");
     const int64_t kpad = t5vq_padded_codes(K);
     const int64_t bx = (N + 3) / 4, bw = (kpad + 3) / 4;
-    if (bx + bw == 0) return T5VQ_OK;
-    T5VQ_REQUIRE(bx + bw < (1LL << 31), "too many rows");
-    hipLaunchKernelGGL(row_sqnorms_kernel, dim3(static_cast<unsigned>(bx + bw)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, N, xx, w, K, kpad, ee, static_cast<int>(D), bx);
+    const int64_t prep_elems = (prep.n_a + prep.n_b) / 4 + prep.n_keys;
+    prep.blocks = 0;
+    if (prep.zero_a || prep.zero_b || prep.keys) {
+        int64_t pb = (prep_elems + 1023) / 1024;  // ~4 stores per thread
+        prep.blocks = static_cast<int>(pb < 1 ? 1 : (pb > 2048 ? 2048 : pb));
+    }
+    if (bx + bw + prep.blocks == 0) return T5VQ_OK;
+    T5VQ_REQUIRE(bx + bw + prep.blocks < (1LL << 31), "too many rows");
+    hipLaunchKernelGGL(row_sqnorms_kernel, dim3(static_cast<unsigned>(bx + bw + prep.blocks)), dim3(256), 0, stream, x,
+                       N, xx, w, K, kpad, ee, static_cast<int>(D), bx, bx + bw, prep);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
+}
+
+int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee, int64_t D,
+                         t5vq_stream_t stream) {
+    return launch_row_sqnorms(x, N, xx, w, K, ee, D, PrepArgs{}, static_cast<hipStream_t>(stream));
 }
 
 int t5vq_dist_argmin_f32(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
@@ -1315,11 +1362,13 @@ int t5vq_unpack_keys(const int64_t* keys, int64_t N, int64_t* idx, float* dmin, 
     return T5VQ_OK;
 }
 
-int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
-                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
-                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
-                          float* loss_partial, t5vq_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+// stats_zeroed: counts / embed_sum were zeroed by the row-norm launch's preparation tail.
+// (Summing the loss partials in the last workgroup to finish -- ticket + device-scope fences -- was measured and
+// rejected: the fences write back L2 and cost 5-80 us, more than the 4 us reduce launch they would replace.)
+static int launch_gather(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
+                         int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
+                         int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
+                         float* loss_partial, bool stats_zeroed, hipStream_t stream) {
     T5VQ_REQUIRE(x && w && keys, "null input");
     T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
     T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
@@ -1331,17 +1380,26 @@ int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, i
     T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
     T5VQ_REQUIRE(stats_begin >= 0 && stats_count >= 0 && stats_begin + stats_count <= K, "stats slice outside [0,K)");
     T5VQ_REQUIRE(!embed_sum || aligned16(embed_sum), "embed_sum must be 16-byte aligned");
-    if (counts && stats_count) T5VQ_CHECK_HIP(hipMemsetAsync(counts, 0, static_cast<size_t>(stats_count) * 4, stream));
-    if (embed_sum && stats_count)
-        T5VQ_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(stats_count) * D * 4, stream));
+    if (!stats_zeroed) {
+        if (counts && stats_count)
+            T5VQ_CHECK_HIP(hipMemsetAsync(counts, 0, static_cast<size_t>(stats_count) * 4, stream));
+        if (embed_sum && stats_count)
+            T5VQ_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(stats_count) * D * 4, stream));
+    }
     const dim3 grid(static_cast<unsigned>(t5vq_gather_blocks(N)));
     const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
     const long long* kp = reinterpret_cast<const long long*>(keys);
     long long* ip = reinterpret_cast<long long*>(idx_out);
-#define T5VQ_GS(NCH_, COS_)                                                                                         \
-    hipLaunchKernelGGL((gather_stats_kernel<NCH_, COS_>), grid, dim3(256), lds, stream, x, w, kp,                   \
+#define T5VQ_GS_T(NCH_, COS_, TOK_)                                                                                 \
+    hipLaunchKernelGGL((gather_stats_kernel<NCH_, COS_, TOK_>), grid, dim3(256), lds, stream, x, w, kp,             \
                        static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), out_ste, out_q, out_diff, ip, \
                        static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial)
+#define T5VQ_GS(NCH_, COS_)                                   \
+    if (gs_tok(N) == GS_TOK_SMALL) {                          \
+        T5VQ_GS_T(NCH_, COS_, GS_TOK_SMALL);                  \
+    } else {                                                  \
+        T5VQ_GS_T(NCH_, COS_, GS_TOK);                        \
+    }
 #define T5VQ_GS_D(COS_)                \
     switch (nch) {                     \
         case 1: T5VQ_GS(1, COS_); break; \
@@ -1357,8 +1415,17 @@ int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, i
     }
 #undef T5VQ_GS_D
 #undef T5VQ_GS
+#undef T5VQ_GS_T
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
+}
+
+int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
+                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
+                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
+                          float* loss_partial, t5vq_stream_t stream) {
+    return launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, stats_begin, stats_count,
+                         counts, embed_sum, loss_partial, false, static_cast<hipStream_t>(stream));
 }
 
 int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream) {
@@ -1419,7 +1486,7 @@ int t5vq_scatter_rows_f32(const float* rows, const int64_t* idx, const float* sc
     const int nch = pick_nch(D);
     T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
     T5VQ_CHECK_HIP(hipMemsetAsync(out, 0, static_cast<size_t>(K) * D * 4, stream));
-    const dim3 grid(static_cast<unsigned>(t5vq_gather_blocks(N)));
+    const dim3 grid(static_cast<unsigned>((N + GS_TOK - 1) / GS_TOK));
     const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
     const long long* ip = reinterpret_cast<const long long*>(idx);
 #define T5VQ_SC(NCH_)                                                                                            \
@@ -1482,28 +1549,39 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
     return FwdWorkspace(N, K).total;
 }
 
+// Four launches: [row norms + buffer preparation] -> [distance + argmin] -> [gather + statistics] -> [loss sum].
 int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
                         int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                        t5vq_stream_t stream) {
+                        t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
     const FwdWorkspace ws(N, K);
     T5VQ_REQUIRE(workspace && aligned16(workspace), "workspace null or not 16-byte aligned");
     T5VQ_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
+    T5VQ_REQUIRE(x && w, "null input");
     char* base = static_cast<char*>(workspace);
     int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
     float* xx = reinterpret_cast<float*>(base + ws.xx);
     float* ee = reinterpret_cast<float*>(base + ws.ee);
     float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
-    int rc = t5vq_row_sqnorms_f32(x, N, xx, w, K, ee, D, stream);
+    PrepArgs prep{};
+    prep.zero_a = counts;
+    prep.n_a = counts ? K : 0;
+    prep.zero_b = embed_sum;
+    prep.n_b = embed_sum ? K * D : 0;
+    prep.keys = reinterpret_cast<long long*>(keys);
+    prep.n_keys = N;
+    int rc = launch_row_sqnorms(x, N, xx, w, K, ee, D, prep, stream);
     if (rc != T5VQ_OK) return rc;
-    rc = t5vq_dist_argmin_f32(x, w, xx, ee, range, N, K, D, 0, 0, keys, stream);
+    t_keys_prefilled = true;
+    rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream);
+    t_keys_prefilled = false;
     if (rc != T5VQ_OK) return rc;
-    rc = t5vq_gather_stats_f32(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts,
-                               embed_sum, partial, stream);
-    if (rc != T5VQ_OK) return rc;
-    if (loss_sum) rc = t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
-    return rc;
+    rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
+                       partial, true, stream);
+    if (rc != T5VQ_OK || !loss_sum) return rc;
+    return t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
 }
 
 int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
