@@ -154,6 +154,23 @@ int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out,
  * reference discards it. */
 int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream);
 
+/* ---- Evaluation-side searches (callers of the path in evaluate_vqvae.py) ----------------
+ *
+ * The topk nearest codes per token in ascending (distance, index) order -- what
+ *   a, idx1 = torch.sort(distances[dim]); idx = idx1[:top_k]          (evaluate_vqvae.py:129-135)
+ * takes from the full get_latent matrix, for every row at once and without the N x K matrix: topk passes of the
+ * fused distance + argmin kernel, pass j admitting only (distance, index) pairs that order after pass j-1's
+ * winner.  keys is [topk, N] (row j = the j-th nearest code of every token); unpack with t5vq_unpack_keys.
+ * Equal distances come out lowest index first (torch.sort leaves their order unspecified). */
+int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
+                       int64_t D, int64_t topk, int64_t* keys, t5vq_stream_t stream);
+
+/* Argmin of a blend of two distance matrices [N,K] (latent-space interpolation, evaluate_vqvae.py:189-200):
+ *   keys[i] = min_k pack(fl(fl(weight_left * dist_left[i,k]) + fl(weight_right * dist_right[i,k])), k)
+ * = torch.argmin(source_t * left_distances + target_t * right_distances, dim=1), first minimum. */
+int t5vq_blend_argmin_f32(const float* dist_left, const float* dist_right, float weight_left, float weight_right,
+                          int64_t N, int64_t K, int64_t* keys, t5vq_stream_t stream);
+
 /* ---- Composite calls: what a replacement of the module's forward must export ------------------
  * They chain the entry points above on `stream`; results are bit-identical to calling them one by one.
  *

@@ -238,6 +238,24 @@ def get_hidden(state: VQState, inputs: torch.Tensor, srl=None, disentanglement=F
 
 # --------------------------------------------------------------------------- closed-form gradients
 
+def topk_codes(state: VQState, inputs: torch.Tensor, top_k: int):
+    """(values, indices) [N, top_k] of the top_k smallest distances per row, ascending, ties lowest index first:
+    ``torch.sort(distances[dim])[:top_k]`` of the traversal (evaluate_vqvae.py:129-135) for every row."""
+    d = get_latent(state, inputs)
+    val, idx = torch.sort(d, dim=1, descending=False, stable=True)
+    return val[:, :top_k], idx[:, :top_k]
+
+
+def blended_indices(state: VQState, source_code: torch.Tensor, target_code: torch.Tensor, source_t: float,
+                    target_t: float) -> torch.Tensor:
+    """One step of the latent-space interpolation (evaluate_vqvae.py:186-200): argmin over codes of
+    ``source_t * d(source_code, W) + target_t * d(target_code, W)``, [N, 1] int64."""
+    w = state.weight
+    left = distances(source_code.reshape(-1, w.shape[1]), w)
+    right = distances(target_code.reshape(-1, w.shape[1]), w)
+    return torch.argmin(source_t * left + target_t * right, dim=1).unsqueeze(1)
+
+
 def grad_inputs_mse(g_q, g_loss, inputs, quantized_raw, commitment_cost):
     """d/dx of [STE output . g_q + g_loss * cc * mse(q.detach(), x)]."""
     return g_q + g_loss * commitment_cost * 2.0 * (inputs - quantized_raw) / inputs.numel()

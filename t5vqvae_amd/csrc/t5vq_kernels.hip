@@ -193,7 +193,9 @@ struct Frag {
     f32x4 a[C::NT];
 };
 
-template <class C, bool RANGED, bool WRITE_DIST>
+// BOUNDED (top-k passes): `range` is reinterpreted as one packed key per token and only (distance, code) pairs that
+// order strictly AFTER that key are admissible -- pass j of a top-k search excludes the j best found so far.
+template <class C, bool RANGED, bool WRITE_DIST, bool BOUNDED = false>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
     const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
@@ -268,9 +270,15 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
         r_start = range[2 * static_cast<size_t>(tok_c)];
         r_end = range[2 * static_cast<size_t>(tok_c) + 1];
     }
+    int bound_s = 0, bound_c = 0;  // BOUNDED: order image of the excluded distance, excluded global code
+    if (BOUNDED) {
+        const long long bk = range[tok_c];
+        bound_s = static_cast<int>(bk >> 32);
+        bound_c = key_index(bk);
+    }
 
     float best = __int_as_float(0x7F800000);
-    int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;  // local code id (before code_offset)
+    int best_code = (RANGED || BOUNDED) ? CODE_NONE : tile_begin * CODE_TILE;  // local code id (before code_offset)
 
     Stage<C> st;
     load_stage(st, 0, 0);
@@ -360,6 +368,15 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
                             const long long gc = code_offset + code;
                             const bool valid = gc >= r_start && gc < r_end && code < K;
                             if (valid && (d < best || best_code == CODE_NONE)) {  // first valid code always taken
+                                best = d;
+                                best_code = code;
+                            }
+                        } else if (BOUNDED) {
+                            const int db = __float_as_int(d);
+                            const int ds = db >= 0 ? db : (db ^ 0x7FFFFFFF);
+                            const int gc = static_cast<int>(code_offset) + code;
+                            const bool valid = code < K && (ds > bound_s || (ds == bound_s && gc > bound_c));
+                            if (valid && (d < best || best_code == CODE_NONE)) {
                                 best = d;
                                 best_code = code;
                             }
@@ -715,6 +732,29 @@ __global__ void unpack_keys_kernel(const long long* __restrict__ keys, long long
     const long long k = keys[i];
     if (idx) idx[i] = key_index(k);
     if (dmin) dmin[i] = key_dist(k);
+}
+
+// keys[i] = min over k of pack(fl(fl(s * dl[i,k]) + fl(t * dr[i,k])), k): one wave per row of two distance matrices
+__global__ __launch_bounds__(256) void blend_argmin_kernel(const float* __restrict__ dl, const float* __restrict__ dr,
+                                                           float s, float t, int N, int K,
+                                                           long long* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* a = dl + row * K;
+    const float* b = dr + row * K;
+    long long best = KEY_NONE;
+    for (int k = lane; k < K; k += 64) {
+        const float d = __fadd_rn(__fmul_rn(s, a[k]), __fmul_rn(t, b[k]));
+        const long long key = pack_key(d, k);
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) keys[row] = best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1166,6 +1206,7 @@ int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time
 }
 
 thread_local bool t_keys_prefilled = false;  // composite forward: keys already hold KEY_NONE
+thread_local bool t_bound = false;           // top-k pass: the range argument holds one excluded key per token
 
 template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
@@ -1180,6 +1221,8 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, true, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         if (V2) {
             T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, false>),
@@ -1216,7 +1259,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
 #define T5VQ_DIST_ARGS                                                                                        \
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
-    const bool v2 = V2 && !dist && D % C::BKC == 0;
+    const bool v2 = V2 && !dist && !t_bound && D % C::BKC == 0;
     const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
     if (v2 && range && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
@@ -1230,6 +1273,9 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     } else if (v2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
+    } else if (t_bound) {  // top-k pass: `range` carries one excluded key per token
+        hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, atomic, kp, dist);
     } else if (dist) {
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, 0, kp, dist);
@@ -1525,6 +1571,32 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
     hipLaunchKernelGGL(one_hot_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const long long*>(idx), static_cast<long long>(N), static_cast<long long>(K),
                        enc);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
+                       int64_t D, int64_t topk, int64_t* keys, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(keys, "keys is null");
+    T5VQ_REQUIRE(topk >= 1 && topk <= K, "topk must be in [1, K]");
+    // pass 0: the plain fused argmin; pass j > 0: the same search restricted to pairs after the pass j-1 winner
+    int rc = launch_dist(x, w, xx, ee, nullptr, N, K, D, 0, 0, keys, nullptr, stream);
+    for (int64_t j = 1; j < topk && rc == T5VQ_OK; ++j) {
+        t_bound = true;
+        rc = launch_dist(x, w, xx, ee, keys + (j - 1) * N, N, K, D, 0, 0, keys + j * N, nullptr, stream);
+        t_bound = false;
+    }
+    return rc;
+}
+
+int t5vq_blend_argmin_f32(const float* dist_left, const float* dist_right, float weight_left, float weight_right,
+                          int64_t N, int64_t K, int64_t* keys, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(dist_left && dist_right && keys, "null pointer");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
+    hipLaunchKernelGGL(blend_argmin_kernel, dim3(static_cast<unsigned>((N + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dist_left, dist_right, weight_left, weight_right,
+                       static_cast<int>(N), static_cast<int>(K), reinterpret_cast<long long*>(keys));
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }

@@ -110,6 +110,37 @@ def distances(x, w, xx, ee):
     return out
 
 
+def dist_topk(x, w, xx, ee, topk: int):
+    """Packed keys [topk, N] of the topk nearest codes per token, nearest first (t5vq_dist_topk_f32)."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d or xx.shape[0] != n or ee.shape[0] != padded_codes(k):
+        raise RuntimeError("dist_topk: inconsistent shapes")
+    if not 1 <= topk <= k:
+        raise RuntimeError(f"topk must be in [1, {k}], got {topk}")
+    keys = torch.empty(topk, n, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_dist_topk_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, topk, _p(keys), _stream(x)),
+                   "dist_topk")
+    return keys
+
+
+def blend_argmin(dist_left, dist_right, weight_left: float, weight_right: float):
+    """Packed keys [N] of argmin_k (weight_left * dist_left + weight_right * dist_right) (t5vq_blend_argmin_f32)."""
+    lib = _lib.load()
+    _need(dist_left, "dist_left", ndim=2), _need(dist_right, "dist_right", ndim=2)
+    if dist_left.shape != dist_right.shape:
+        raise RuntimeError("blend_argmin: the two distance matrices differ in shape")
+    n, k = dist_left.shape
+    keys = torch.empty(n, dtype=torch.int64, device=dist_left.device)
+    with torch.cuda.device(dist_left.device):
+        _lib.check(lib.t5vq_blend_argmin_f32(_p(dist_left), _p(dist_right), weight_left, weight_right, n, k,
+                                             _p(keys), _stream(dist_left)), "blend_argmin")
+    return keys
+
+
 def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, idx=None, counts=None,
                  embed_sum=None, loss_partial=None, stats_begin: int = 0, stats_count: Optional[int] = None):
     """Every output is optional and caller-allocated (None = not produced)."""

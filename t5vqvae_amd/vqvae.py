@@ -213,6 +213,36 @@ class _QuantizerBase(nn.Module):
         ops.gather_stats(flat, w, keys, "mse", q=q)
         return q.view(inputs.shape)
 
+    # --- evaluation-side searches (callers in evaluate_vqvae.py; no counterpart method in vqvae/vqvae.py) ----
+    @torch.no_grad()
+    def topk_codes(self, inputs, top_k: int):
+        """(distances [N, top_k], indices [N, top_k]) of the top_k nearest codes per token, nearest first: the
+        ``torch.sort(get_latent(x)[dim])[:top_k]`` of the traversal (evaluate_vqvae.py:129-135) for every row at
+        once, without the N x K matrix."""
+        flat = inputs.view(-1, self._embedding_dim).contiguous()
+        w = self._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, w)
+        keys = ops.dist_topk(flat, w, xx, ee, int(top_k))
+        idx, dmin = ops.unpack_keys(keys.view(-1), want_idx=True, want_dmin=True)
+        n = flat.shape[0]
+        return dmin.view(top_k, n).t().contiguous(), idx.view(top_k, n).t().contiguous()
+
+    @torch.no_grad()
+    def blended_indices(self, source_code, target_code, source_t: float, target_t: float):
+        """Indices [N, 1] of ``argmin(source_t * d(source_code, W) + target_t * d(target_code, W))``: one step of
+        the latent-space interpolation (evaluate_vqvae.py:186-200).  The two [N, K] distance matrices are formed
+        (as the reference does; N is one sentence there) and blended in the reference's rounding order."""
+        a = source_code.reshape(-1, self._embedding_dim).contiguous()
+        b = target_code.reshape(-1, self._embedding_dim).contiguous()
+        if a.shape != b.shape:
+            raise RuntimeError("source_code and target_code must have the same number of rows")
+        w = self._embedding.weight.detach()
+        aa, ee = ops.row_sqnorms(a, w)
+        bb, _ = ops.row_sqnorms(b, None)
+        keys = ops.blend_argmin(ops.distances(a, w, aa, ee), ops.distances(b, w, bb, ee), float(source_t),
+                                float(target_t))
+        return ops.unpack_keys(keys)[0].unsqueeze(1)
+
 
 class VectorQuantizer(_QuantizerBase):
     """Codebook learned by gradient (vqvae/vqvae.py:6-76).  ``**kwargs`` are accepted and ignored, as in the

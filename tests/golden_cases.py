@@ -38,6 +38,7 @@ class Case:
     init: str = "cold"                    # cold | clustered | ties | small
     data: str = "normal"                  # normal | clustered | c1 | ties
     methods: bool = False                 # also record get_latent / get_indices / get_hidden
+    searches: bool = False                # also record the evaluation-side searches (top-k, blended argmin)
     seed: int = 0
     cc: float = 0.25
     decay: float = 0.99
@@ -67,6 +68,7 @@ CASES = {c.name: c for c in [
          seed=109),
     Case("G10_shape_1x45", "VectorQuantizerEMA", 512, 768, (1, 45), seed=110),
     Case("G11_small_dim", "VectorQuantizerEMA", 100, 64, (3, 50), steps=2, seed=111),
+    Case("G12_eval_searches", "VectorQuantizerEMA", 1000, 768, (1, 45), training=False, searches=True, seed=112),
 ]}
 
 
@@ -155,6 +157,8 @@ def run_case(c: Case, factory: Callable, device: str = "cpu") -> dict:
             out[f"s{t}_latent"] = mod.get_latent(x).detach().cpu()
             out[f"s{t}_get_indices"] = mod.get_indices(x, srl).detach().cpu()
             out[f"s{t}_hidden"] = mod.get_hidden(x, srl).detach().cpu()
+        if c.searches:
+            out.update(run_searches(mod, x, synth.normal((*c.shape, c.D), c.seed, 70 + t).to(device), t))
         loss, q, ppl, enc = mod(x, srl)
         out[f"s{t}_loss"] = loss.detach().cpu().reshape(1)
         out[f"s{t}_perplexity"] = ppl.detach().cpu().reshape(1)
@@ -175,6 +179,41 @@ def run_case(c: Case, factory: Callable, device: str = "cpu") -> dict:
     sd = mod.state_dict()
     for k, v in sd.items():
         out["final." + k] = v.detach().cpu().clone()
+    return out
+
+
+SEARCH_TOP_K = 10
+# not 0.5: both inputs are codebook rows there, so d(a,b) = d(b,a) makes the two candidates an exact symmetric tie
+# that only rounding noise decides (in the reference as well)
+BLEND_STEPS = (0.0, 0.3, 0.6, 1.0)
+
+
+def run_searches(mod, x, x2, t) -> dict:
+    """The two searches evaluate_vqvae.py runs on top of the module.  An implementation that offers them as
+    methods (``topk_codes``, ``blended_indices``) is driven through those; the reference module is driven through
+    the caller-side torch expressions the script uses (restated here from evaluate_vqvae.py:129-135 and :182-200)."""
+    out = {}
+    with torch.no_grad():
+        if hasattr(mod, "topk_codes"):
+            val, idx = mod.topk_codes(x, SEARCH_TOP_K)
+        else:
+            dist = mod.get_latent(x)                                   # :129
+            val, idx = torch.sort(dist, dim=1, descending=False)       # :134, for every row `dim` at once
+            val, idx = val[:, :SEARCH_TOP_K], idx[:, :SEARCH_TOP_K]    # :135
+        out[f"s{t}_topk_val"] = val.detach().cpu()
+        out[f"s{t}_topk_idx"] = idx.detach().to(torch.int32).cpu()
+        src = mod(x)[1].squeeze(0)                                     # :182
+        tgt = mod(x2)[1].squeeze(0)                                    # :183
+        for z in BLEND_STEPS:
+            source_t, target_t = 1 - z, z                              # :186-187
+            if hasattr(mod, "blended_indices"):
+                bi = mod.blended_indices(src, tgt, source_t, target_t)
+            else:
+                w = mod._embedding.weight
+                left = (src ** 2).sum(1, keepdim=True) + (w ** 2).sum(1) - 2 * torch.matmul(src, w.t())    # :189
+                right = (tgt ** 2).sum(1, keepdim=True) + (w ** 2).sum(1) - 2 * torch.matmul(tgt, w.t())   # :190
+                bi = torch.argmin(source_t * left + target_t * right, dim=1).unsqueeze(1)                  # :191,200
+            out[f"s{t}_blend{int(z * 10):02d}_idx"] = bi.detach().to(torch.int32).cpu()
     return out
 
 

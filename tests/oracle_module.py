@@ -54,6 +54,13 @@ class OracleQuantizer(nn.Module):
         return vo.get_hidden(self._state(), inputs, srl, self.disentanglement)
 
 
+    def topk_codes(self, inputs, top_k):
+        return vo.topk_codes(self._state(), inputs, top_k)
+
+    def blended_indices(self, source_code, target_code, source_t, target_t):
+        return vo.blended_indices(self._state(), source_code, target_code, source_t, target_t)
+
+
 def factory(path):
     def make(cls, **kw):
         return OracleQuantizer(cls, path=path, **kw)

@@ -62,6 +62,9 @@ def test_hip_matches_reference_golden(name):
     if diverged:
         pytest.skip(f"{name}: in-band index mismatches {report}; downstream tensors checked in test_gpu_parity")
     for key in sorted(exp):
+        if key.endswith("_topk_idx") or "_blend" in key:      # evaluation-side searches: exact
+            assert np.array_equal(got[key].numpy().ravel(), exp[key]["full"].ravel()), key
+            continue
         if key.endswith("_idx"):
             continue
         if key.endswith("_get_indices"):

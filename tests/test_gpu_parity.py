@@ -339,3 +339,54 @@ def test_module_step_replays_from_a_hip_graph():
             assert rel(out[1], ref[1]) < 1e-6 and rel(out[0], ref[0]) < 1e-6 and rel(out[2], ref[2]) < 1e-6
             assert rel(m1._embedding.weight.data, m2._embedding.weight.data) < 1e-6
             assert rel(m1._ema_cluster_size, m2._ema_cluster_size) < 1e-7
+
+
+@pytest.mark.parametrize("n,k,d,topk", [(45, 10000, 768, 10), (300, 257, 64, 257), (2880, 1000, 768, 3)])
+def test_topk_codes_vs_oracle(n, k, d, topk):
+    """top-k search without the N x K matrix == stable sort of the oracle's distance rows (ties lowest index first);
+    duplicated codebook rows make exact ties certain."""
+    m, st = make_ema(k, d, 21)
+    with torch.no_grad():
+        m._embedding.weight[k // 2] = m._embedding.weight[3]
+        m._embedding.weight[k - 1] = m._embedding.weight[3]
+    st.weight[k // 2] = st.weight[3]
+    st.weight[k - 1] = st.weight[3]
+    x = synth.normal((n, d), 22, 0)
+    val, idx = m.topk_codes(x.cuda(), topk)
+    assert val.shape == (n, topk) and idx.shape == (n, topk)
+    val, idx = val.cpu(), idx.cpu()
+    d64 = vo.distances_fp64(x, st.weight)
+    # order: the kernel's own distances must be ascending, ties by index; values must be the distances of idx
+    assert bool((val[:, 1:] >= val[:, :-1]).all())
+    tie = val[:, 1:] == val[:, :-1]
+    assert bool((idx[:, 1:][tie] > idx[:, :-1][tie]).all())
+    assert len(set(idx[0].tolist())) == topk
+    assert rel(val, d64.gather(1, idx)) <= TOL
+    # membership: every returned code is within the band of the oracle's top-k threshold
+    ref_val, ref_idx = vo.topk_codes(st, x, topk)
+    band = 1e-6 * ((x.double() ** 2).sum(1) + (st.weight.double() ** 2).sum(1).max())
+    kth = torch.sort(d64, dim=1).values[:, topk - 1]
+    assert bool((d64.gather(1, idx) <= (kth + band).unsqueeze(1)).all())
+    # rank by rank: a code different from the oracle's must be a near-tie of it (fp64 distances within the band)
+    gap = (d64.gather(1, idx) - d64.gather(1, ref_idx)).abs()
+    assert bool((gap[idx != ref_idx] <= band.unsqueeze(1).expand_as(gap)[idx != ref_idx]).all())
+    assert int((idx != ref_idx).sum()) <= 0.01 * idx.numel() + 2
+    if topk == k:                                         # a full sort is a permutation of all codes
+        assert bool((torch.sort(idx, dim=1).values == torch.arange(k)).all())
+
+
+def test_blended_indices_vs_oracle():
+    n, k, d = 45, 10000, 768
+    m, st = make_ema(k, d, 23)
+    a, b = synth.normal((n, d), 24, 0), synth.normal((n, d), 24, 1)
+    for z in (0.0, 0.1, 0.5, 0.9, 1.0):
+        got = m.blended_indices(a.cuda(), b.cuda(), 1 - z, z).cpu()
+        ref = vo.blended_indices(st, a, b, 1 - z, z)
+        assert got.shape == (n, 1) and got.dtype == torch.int64
+        bad = (got != ref).nonzero()[:, 0]
+        if len(bad):                                       # accept only near-ties of the blended distance
+            dl, dr = vo.distances_fp64(a, st.weight), vo.distances_fp64(b, st.weight)
+            bl = (1 - z) * dl + z * dr
+            gap = (bl.gather(1, got) - bl.gather(1, ref)).abs().squeeze(1)[bad]
+            band = 1e-6 * ((a.double() ** 2).sum(1) + (b.double() ** 2).sum(1) + (st.weight.double() ** 2).sum(1).max())
+            assert bool((gap <= band[bad]).all())
