@@ -171,6 +171,28 @@ int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const fl
 int t5vq_blend_argmin_f32(const float* dist_left, const float* dist_right, float weight_left, float weight_right,
                           int64_t N, int64_t K, int64_t* keys, t5vq_stream_t stream);
 
+/* ---- Encoder tail fused into the VQ prologue ------------------------------------------
+ *
+ * T5LayerNorm (python_transformers/modeling_t5.py:191-207: no mean subtraction, learned scale) followed by dropout
+ * (:864-865, and :853-854 at the mid-encoder call site) produce the tensor the VQ receives (t5/load_t5.py:518).
+ * One pass over `hidden` [N,D] writes that tensor AND its row norms, so t5vq_row_sqnorms_f32 need not re-read it:
+ *   r_i = sqrt(mean_d hidden[i,d]^2 + eps);  y = gamma * (hidden / r_i)          (the reference's op order)
+ *   x_out = keep ? (keep[i,d] ? y * scale : 0) : y       keep: uint8 [N,D] mask, nullable (eval / p = 0);
+ *                                                        scale = 1 / (1 - p), as torch's dropout applies it
+ *   xx[i] = sum_d x_out[i,d]^2 (nullable);   rms[i] = r_i (nullable; saved for backward)
+ * The mask is an input (drawn by the caller's RNG): bit parity with torch's Philox stream is not a goal. */
+int t5vq_rmsnorm_sqnorms_f32(const float* hidden, const float* gamma, const uint8_t* keep, float scale, float eps,
+                             int64_t N, int64_t D, float* x_out, float* xx, float* rms, t5vq_stream_t stream);
+
+/* Autograd of the above:  gy = grad_x * keep * scale;  a = gy * gamma;
+ *   grad_hidden = a / r - hidden * (sum_d a_d hidden_d) / (D r^3);   grad_gamma[d] = sum_i gy[i,d] hidden[i,d] / r_i
+ * grad_gamma is nullable; when given, `workspace` holds t5vq_rmsnorm_backward_blocks(N) * D floats of per-workgroup
+ * partial sums that a second launch adds in fixed order (deterministic, no atomics). */
+int64_t t5vq_rmsnorm_backward_blocks(int64_t N);
+int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const float* gamma, const uint8_t* keep,
+                              float scale, const float* rms, int64_t N, int64_t D, float* grad_hidden,
+                              float* grad_gamma, float* workspace, t5vq_stream_t stream);
+
 /* ---- Composite calls: what a replacement of the module's forward must export ------------------
  * They chain the entry points above on `stream`; results are bit-identical to calling them one by one.
  *
@@ -179,11 +201,12 @@ int t5vq_blend_argmin_f32(const float* dist_left, const float* dist_right, float
  * counts / embed_sum -> loss_sum[0] = sum of the loss terms.  `workspace` holds the per-call temporaries
  * (keys, |x|^2, |e|^2, loss partials): t5vq_forward_workspace_bytes(N, K) bytes, 16-byte aligned, caller-owned.
  * range, out_ste, out_q, out_diff, idx_out, counts, embed_sum, loss_sum are nullable as in
- * t5vq_dist_argmin_f32 / t5vq_gather_stats_f32.  Whole-codebook form (code_offset 0, statistics for [0,K));
+ * t5vq_dist_argmin_f32 / t5vq_gather_stats_f32.  xx_in (nullable): |x_i|^2 [N] already computed by the producer of
+ * x (t5vq_rmsnorm_sqnorms_f32); the pass over x for the row norms is then skipped.  Whole-codebook form (code_offset 0, statistics for [0,K));
  * a code-sharded caller uses the fine-grained calls. */
 int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K);
-int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
-                        int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
+                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
                         t5vq_stream_t stream);
 

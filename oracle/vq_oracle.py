@@ -256,6 +256,26 @@ def blended_indices(state: VQState, source_code: torch.Tensor, target_code: torc
     return torch.argmin(source_t * left + target_t * right, dim=1).unsqueeze(1)
 
 
+def t5_layer_norm(hidden: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """T5LayerNorm.forward, python_transformers/modeling_t5.py:200-207 (fp32 branch): RMS norm without mean
+    subtraction, learned scale.  PARITY UNPINNED against the reference: python_transformers does not import here
+    (ModuleNotFoundError: sacremoses), so this restatement is checked against the cited lines only."""
+    variance = hidden.to(torch.float32).pow(2).mean(-1, keepdim=True)       # :202
+    x = hidden / torch.sqrt(variance + eps)                                 # :203
+    return weight * x                                                       # :207
+
+
+def encoder_tail(hidden: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, keep: Optional[torch.Tensor] = None,
+                 p: float = 0.1) -> torch.Tensor:
+    """``dropout(final_layer_norm(hidden_states))`` (modeling_t5.py:864-865; :853-854 at the mid-encoder call site)
+    with the dropout mask made explicit: ``keep`` is the 0/1 mask torch would draw, survivors are scaled by
+    ``1 / (1 - p)`` (torch.nn.functional.dropout).  keep=None: evaluation mode (identity)."""
+    y = t5_layer_norm(hidden, weight, eps)
+    if keep is None:
+        return y
+    return y * (keep.to(y.dtype) * torch.tensor(1.0 / (1.0 - p), dtype=y.dtype))
+
+
 def grad_inputs_mse(g_q, g_loss, inputs, quantized_raw, commitment_cost):
     """d/dx of [STE output . g_q + g_loss * cc * mse(q.detach(), x)]."""
     return g_q + g_loss * commitment_cost * 2.0 * (inputs - quantized_raw) / inputs.numel()

@@ -37,8 +37,11 @@ SIGNATURES = {
     "t5vq_one_hot_f32": (c_int, [P, I64, I64, P, P]),
     "t5vq_dist_topk_f32": (c_int, [P, P, P, P, I64, I64, I64, I64, P, P]),
     "t5vq_blend_argmin_f32": (c_int, [P, P, c_float, c_float, I64, I64, P, P]),
+    "t5vq_rmsnorm_sqnorms_f32": (c_int, [P, P, P, c_float, c_float, I64, I64, P, P, P, P]),
+    "t5vq_rmsnorm_backward_blocks": (I64, [I64]),
+    "t5vq_rmsnorm_backward_f32": (c_int, [P, P, P, P, c_float, P, I64, I64, P, P, P, P]),
     "t5vq_forward_workspace_bytes": (I64, [I64, I64]),
-    "t5vq_vq_forward_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P]),
+    "t5vq_vq_forward_f32": (c_int, [P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P]),
     "t5vq_vq_ema_finalize_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, c_float, c_float, c_float, c_float,
                                          c_float, c_float, c_int, c_int, P, P]),
 }

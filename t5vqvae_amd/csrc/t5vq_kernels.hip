@@ -1005,6 +1005,144 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Encoder tail fused into the VQ prologue: T5LayerNorm (RMS norm, no mean subtraction, learned
+// scale) + dropout produce the VQ input; the same pass also emits the row norms |x|^2 the distance kernel needs.
+// One wave per row; lane layout as everywhere: float4 #(j*64 + lane).
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_sqnorms_kernel(const float* __restrict__ hid,
+                                                              const float* __restrict__ gamma,
+                                                              const unsigned char* __restrict__ keep, float scale,
+                                                              float eps, int N, int D, float* __restrict__ x_out,
+                                                              float* __restrict__ xx, float* __restrict__ rms_out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const f32x4* hr = reinterpret_cast<const f32x4*>(hid + row * D);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hv[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c4 = j * 64 + lane;
+        hv[j] = (c4 * 4 < D) ? hr[c4] : zero4;
+        ss = fmaf(hv[j].x, hv[j].x, ss);
+        ss = fmaf(hv[j].y, hv[j].y, ss);
+        ss = fmaf(hv[j].z, hv[j].z, ss);
+        ss = fmaf(hv[j].w, hv[j].w, ss);
+    }
+    ss = wave_sum(ss);
+    const float var = __fdiv_rn(ss, static_cast<float>(D));   // x.pow(2).mean(-1)
+    const float r = __fsqrt_rn(__fadd_rn(var, eps));           // sqrt(variance + eps)
+    if (rms_out && lane == 0) rms_out[row] = r;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c4 = j * 64 + lane;
+        if (c4 * 4 < D) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4];
+            f32x4 y;
+            y.x = __fmul_rn(g.x, __fdiv_rn(hv[j].x, r));       // weight * (x / sqrt(...))
+            y.y = __fmul_rn(g.y, __fdiv_rn(hv[j].y, r));
+            y.z = __fmul_rn(g.z, __fdiv_rn(hv[j].z, r));
+            y.w = __fmul_rn(g.w, __fdiv_rn(hv[j].w, r));
+            if (keep) {
+                const uchar4 m = reinterpret_cast<const uchar4*>(keep + row * D)[c4];
+                y.x = m.x ? __fmul_rn(y.x, scale) : 0.f;
+                y.y = m.y ? __fmul_rn(y.y, scale) : 0.f;
+                y.z = m.z ? __fmul_rn(y.z, scale) : 0.f;
+                y.w = m.w ? __fmul_rn(y.w, scale) : 0.f;
+            }
+            reinterpret_cast<f32x4*>(x_out + row * D)[c4] = y;
+            s2 = fmaf(y.x, y.x, s2);
+            s2 = fmaf(y.y, y.y, s2);
+            s2 = fmaf(y.z, y.z, s2);
+            s2 = fmaf(y.w, y.w, s2);
+        }
+    }
+    s2 = wave_sum(s2);
+    if (xx && lane == 0) xx[row] = s2;
+}
+
+// Backward of the tail.  With gy = g * keep * scale, a = gy * gamma, r = sqrt(mean(h^2) + eps):
+//   grad_h = a / r - h * (sum_d a_d h_d) / (D r^3);   grad_gamma = sum_rows gy * h / r.
+// A workgroup walks rows [blockIdx, blockIdx + gridDim, ...) (4 at a time, one per wave) and leaves ONE partial
+// grad_gamma row in gw_partial[blockIdx]; rmsnorm_gamma_reduce_kernel sums the partials in fixed order.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_backward_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ hid,
+                                                               const float* __restrict__ gamma,
+                                                               const unsigned char* __restrict__ keep, float scale,
+                                                               const float* __restrict__ rms, int N, int D,
+                                                               float* __restrict__ grad_h,
+                                                               float* __restrict__ gw_partial) {
+    extern __shared__ __attribute__((aligned(16))) float tbuf[];  // [4 waves][NCH*256]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gam[NCH], gw[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c4 = j * 64 + lane;
+        gam[j] = (c4 * 4 < D) ? reinterpret_cast<const f32x4*>(gamma)[c4] : zero4;
+        gw[j] = zero4;
+    }
+    const float inv_d = 1.0f / static_cast<float>(D);
+    for (long long row = static_cast<long long>(blockIdx.x) * 4 + wave; row < N;
+         row += static_cast<long long>(gridDim.x) * 4) {
+        const float r = rms[row];
+        const float inv_r = 1.0f / r;
+        f32x4 a[NCH], hv[NCH];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c4 = j * 64 + lane;
+            a[j] = zero4;
+            hv[j] = zero4;
+            if (c4 * 4 < D) {
+                f32x4 gy = reinterpret_cast<const f32x4*>(g + row * D)[c4];
+                hv[j] = reinterpret_cast<const f32x4*>(hid + row * D)[c4];
+                if (keep) {
+                    const uchar4 m = reinterpret_cast<const uchar4*>(keep + row * D)[c4];
+                    gy.x = m.x ? gy.x * scale : 0.f;
+                    gy.y = m.y ? gy.y * scale : 0.f;
+                    gy.z = m.z ? gy.z * scale : 0.f;
+                    gy.w = m.w ? gy.w * scale : 0.f;
+                }
+                a[j] = gy * gam[j];
+                dot += a[j].x * hv[j].x + a[j].y * hv[j].y + a[j].z * hv[j].z + a[j].w * hv[j].w;
+                gw[j] += gy * hv[j] * inv_r;
+            }
+        }
+        dot = wave_sum(dot);
+        const float c = dot * inv_d * inv_r * inv_r * inv_r;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c4 = j * 64 + lane;
+            if (c4 * 4 < D) reinterpret_cast<f32x4*>(grad_h + row * D)[c4] = a[j] * inv_r - hv[j] * c;
+        }
+    }
+    if (!gw_partial) return;
+    // sum the four waves' partial grad_gamma rows through LDS, fixed order
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) reinterpret_cast<f32x4*>(tbuf + wave * (NCH * 256))[j * 64 + lane] = gw[j];
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+        const float v = (tbuf[col] + tbuf[NCH * 256 + col]) + (tbuf[2 * NCH * 256 + col] + tbuf[3 * NCH * 256 + col]);
+        gw_partial[static_cast<size_t>(blockIdx.x) * D + col] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_gamma_reduce_kernel(const float* __restrict__ gw_partial, int G, int D,
+                                                                   float* __restrict__ grad_gamma) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= D) return;
+    float acc = 0.f;
+    for (int b = 0; b < G; ++b) acc += gw_partial[static_cast<size_t>(b) * D + col];
+    grad_gamma[col] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward helpers
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ste_backward_kernel(const float* __restrict__ g_out,
@@ -1575,6 +1713,71 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
     return T5VQ_OK;
 }
 
+int64_t t5vq_rmsnorm_backward_blocks(int64_t N) {
+    const int64_t b = (N + 3) / 4;
+    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+
+int t5vq_rmsnorm_sqnorms_f32(const float* hidden, const float* gamma, const uint8_t* keep, float scale, float eps,
+                             int64_t N, int64_t D, float* x_out, float* xx, float* rms, t5vq_stream_t stream) {
+    T5VQ_REQUIRE(hidden && gamma && x_out, "null pointer");
+    T5VQ_REQUIRE(N > 0 && N < (1LL << 31) && D > 0 && D % 4 == 0, "N, D out of range");
+    T5VQ_REQUIRE(aligned16(hidden) && aligned16(gamma) && aligned16(x_out), "16-byte alignment");
+    T5VQ_REQUIRE(!keep || (reinterpret_cast<uintptr_t>(keep) & 3u) == 0, "keep mask must be 4-byte aligned");
+    const int nch = pick_nch(D);
+    T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
+    const dim3 grid(static_cast<unsigned>((N + 3) / 4));
+#define T5VQ_RN(NCH_)                                                                                              \
+    hipLaunchKernelGGL((rmsnorm_sqnorms_kernel<NCH_>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), hidden, \
+                       gamma, keep, scale, eps, static_cast<int>(N), static_cast<int>(D), x_out, xx, rms)
+    switch (nch) {
+        case 1: T5VQ_RN(1); break;
+        case 2: T5VQ_RN(2); break;
+        case 3: T5VQ_RN(3); break;
+        case 4: T5VQ_RN(4); break;
+        default: T5VQ_RN(8); break;
+    }
+#undef T5VQ_RN
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const float* gamma, const uint8_t* keep,
+                              float scale, const float* rms, int64_t N, int64_t D, float* grad_hidden,
+                              float* grad_gamma, float* workspace, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(grad_x && hidden && gamma && rms && grad_hidden, "null pointer");
+    T5VQ_REQUIRE(!grad_gamma || workspace, "grad_gamma needs the [t5vq_rmsnorm_backward_blocks(N), D] workspace");
+    T5VQ_REQUIRE(N > 0 && N < (1LL << 31) && D > 0 && D % 4 == 0, "N, D out of range");
+    T5VQ_REQUIRE(aligned16(grad_x) && aligned16(hidden) && aligned16(gamma) && aligned16(grad_hidden) &&
+                     (!workspace || aligned16(workspace)), "16-byte alignment");
+    T5VQ_REQUIRE(!keep || (reinterpret_cast<uintptr_t>(keep) & 3u) == 0, "keep mask must be 4-byte aligned");
+    const int nch = pick_nch(D);
+    T5VQ_REQUIRE(nch > 0, "D > 2048 is not supported");
+    const int64_t blocks = t5vq_rmsnorm_backward_blocks(N);
+    const dim3 grid(static_cast<unsigned>(blocks));
+    const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
+    float* part = grad_gamma ? workspace : nullptr;
+#define T5VQ_RB(NCH_)                                                                                           \
+    hipLaunchKernelGGL((rmsnorm_backward_kernel<NCH_>), grid, dim3(256), lds, stream, grad_x, hidden, gamma, keep, \
+                       scale, rms, static_cast<int>(N), static_cast<int>(D), grad_hidden, part)
+    switch (nch) {
+        case 1: T5VQ_RB(1); break;
+        case 2: T5VQ_RB(2); break;
+        case 3: T5VQ_RB(3); break;
+        case 4: T5VQ_RB(4); break;
+        default: T5VQ_RB(8); break;
+    }
+#undef T5VQ_RB
+    T5VQ_CHECK_HIP(hipGetLastError());
+    if (grad_gamma) {
+        hipLaunchKernelGGL(rmsnorm_gamma_reduce_kernel, dim3(static_cast<unsigned>((D + 255) / 256)), dim3(256), 0,
+                           stream, part, static_cast<int>(blocks), static_cast<int>(D), grad_gamma);
+        T5VQ_CHECK_HIP(hipGetLastError());
+    }
+    return T5VQ_OK;
+}
+
 int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
                        int64_t D, int64_t topk, int64_t* keys, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1622,8 +1825,8 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
 }
 
 // Four launches: [row norms + buffer preparation] -> [distance + argmin] -> [gather + statistics] -> [loss sum].
-int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
-                        int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
+                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
                         t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1634,7 +1837,7 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, in
     T5VQ_REQUIRE(x && w, "null input");
     char* base = static_cast<char*>(workspace);
     int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
-    float* xx = reinterpret_cast<float*>(base + ws.xx);
+    const float* xx = xx_in ? xx_in : reinterpret_cast<float*>(base + ws.xx);
     float* ee = reinterpret_cast<float*>(base + ws.ee);
     float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
     PrepArgs prep{};
@@ -1644,7 +1847,9 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, in
     prep.n_b = embed_sum ? K * D : 0;
     prep.keys = reinterpret_cast<long long*>(keys);
     prep.n_keys = N;
-    int rc = launch_row_sqnorms(x, N, xx, w, K, ee, D, prep, stream);
+    // |x|^2 may come from the producer of x (t5vq_rmsnorm_sqnorms_f32): then only |e|^2 is computed here
+    int rc = xx_in ? launch_row_sqnorms(nullptr, 0, nullptr, w, K, ee, D, prep, stream)
+                   : launch_row_sqnorms(x, N, reinterpret_cast<float*>(base + ws.xx), w, K, ee, D, prep, stream);
     if (rc != T5VQ_OK) return rc;
     t_keys_prefilled = true;
     rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream);

@@ -1,0 +1,71 @@
+"""Encoder tail fused into the VQ prologue.
+
+In the reference the tensor the VQ receives is ``dropout(final_layer_norm(hidden_states))``
+(python_transformers/modeling_t5.py:864-865, consumed at t5/load_t5.py:518; the mid-encoder call site applies the
+same two ops first, :853-855).  ``T5LayerNorm`` is an RMS norm: ``weight * (x / sqrt(mean(x^2) + eps))``
+(:191-207).  In eager PyTorch that tail is half a dozen elementwise passes over [N, D], and the VQ then reads the
+result once more just to form |x|^2.  ``EncoderTailVQ`` does norm + dropout + |x|^2 in ONE pass
+(``t5vq_rmsnorm_sqnorms_f32``) and hands both to the quantizer; its backward (``t5vq_rmsnorm_backward_f32``)
+returns the gradients of the hidden states and of the norm weight.
+
+A maintainer who wants the fusion replaces ``final_layer_norm`` / ``dropout`` of the encoder stack by identities
+and calls this module where ``self.vqvae(encoding, srl_ids)`` is called.  The plain
+drop-in (``VectorQuantizerEMA`` alone) does not need it.
+
+The dropout mask is drawn with torch's generator (``bernoulli_``) and passed to the kernel as a uint8 tensor, or
+given by the caller (``keep_mask=``); torch's own fused dropout draws a different Philox stream, so masks -- not
+results for a given mask -- differ from eager ``nn.Dropout``.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class _TailFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, gamma, keep, scale, eps):
+        x, xx, rms = ops.rmsnorm_sqnorms(hidden, gamma.detach(), keep, scale, eps, want_rms=True)
+        ctx.save_for_backward(hidden, gamma.detach(), keep, rms)
+        ctx.scale = scale
+        ctx.mark_non_differentiable(xx)
+        return x, xx
+
+    @staticmethod
+    def backward(ctx, g_x, g_xx):
+        hidden, gamma, keep, rms = ctx.saved_tensors
+        gh, gg = ops.rmsnorm_backward(g_x, hidden, gamma, keep, ctx.scale, rms,
+                                      want_grad_gamma=ctx.needs_input_grad[1])
+        return (gh if ctx.needs_input_grad[0] else None), gg, None, None, None
+
+
+class EncoderTailVQ(nn.Module):
+    """``vq(dropout(T5LayerNorm(hidden_states)), srl)`` with the norm, the dropout and the row norms in one kernel.
+
+    ``vq``: a ``t5vqvae_amd`` quantizer module.  ``weight``: the ``final_layer_norm.weight`` Parameter to share (so
+    checkpoints keep their key), or None for a fresh ``ones(hidden_size)`` (modeling_t5.py:197)."""
+
+    def __init__(self, vq, hidden_size: int = 768, eps: float = 1e-6, dropout_rate: float = 0.1, weight=None):
+        super().__init__()
+        self.vq = vq
+        self.weight = weight if weight is not None else nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+        self.dropout_rate = float(dropout_rate)
+
+    def forward(self, hidden_states, srl=None, keep_mask=None):
+        d = hidden_states.shape[-1]
+        flat = hidden_states.reshape(-1, d)
+        if flat.dtype != torch.float32:
+            raise RuntimeError(f"hidden_states must be float32 (got {flat.dtype})")
+        flat = flat.contiguous()
+        keep, scale = None, 1.0
+        if keep_mask is not None:
+            keep = keep_mask.reshape(-1, d).to(torch.uint8).contiguous()
+            scale = 1.0 / (1.0 - self.dropout_rate)
+        elif self.training and self.dropout_rate > 0.0:
+            keep = torch.empty(flat.shape, dtype=torch.uint8, device=flat.device).bernoulli_(1.0 - self.dropout_rate)
+            scale = 1.0 / (1.0 - self.dropout_rate)
+        x, xx = _TailFunction.apply(flat, self.weight, keep, scale, float(self.variance_epsilon))
+        return self.vq(x.view(hidden_states.shape), srl, _xx=xx)

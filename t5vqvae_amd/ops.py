@@ -169,8 +169,8 @@ def forward_workspace_bytes(n: int, k: int) -> int:
     return int(_lib.load().t5vq_forward_workspace_bytes(n, k))
 
 
-def vq_forward(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
-               loss_sum=None):
+def vq_forward(x, w, ranges, loss: str, *, xx=None, ste=None, q=None, diff=None, idx=None, counts=None,
+               embed_sum=None, loss_sum=None):
     """The whole forward behind one host call (t5vq_vq_forward_f32): row norms, distance + argmin, gather /
     straight-through / loss terms / EMA statistics, loss_sum.  Outputs are optional and caller-allocated."""
     lib = _lib.load()
@@ -183,7 +183,7 @@ def vq_forward(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None
         _need(ranges, "ranges", torch.int64, 2)
         if tuple(ranges.shape) != (n, 2):
             raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
-    for name, t, numel in (("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
+    for name, t, numel in (("xx", xx, n), ("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
                            ("embed_sum", embed_sum, k * d), ("loss_sum", loss_sum, 1)):
         if t is not None:
             _need(t, name)
@@ -196,7 +196,7 @@ def vq_forward(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None
     nbytes = forward_workspace_bytes(n, k)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
+        _lib.check(lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), _p(xx), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
                                            _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
                                            _p(loss_sum), _stream(x)), "vq_forward")
 
@@ -222,6 +222,43 @@ def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: 
                                                 loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
                                                 commitment_cost, 1 if plain_variant else 0, 1 if update else 0,
                                                 _p(scalars), _stream(scalars)), "ema_finalize")
+
+
+def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: bool = True):
+    """(x, xx, rms): T5LayerNorm + dropout mask + row norms of the result in one pass (t5vq_rmsnorm_sqnorms_f32)."""
+    lib = _lib.load()
+    _need(hidden, "hidden", ndim=2), _need(gamma, "gamma", ndim=1)
+    n, d = hidden.shape
+    if gamma.shape[0] != d:
+        raise RuntimeError(f"gamma must have {d} elements")
+    if keep is not None:
+        _need(keep, "keep", torch.uint8, 2)
+        if tuple(keep.shape) != (n, d):
+            raise RuntimeError(f"keep must be [{n}, {d}]")
+    x = torch.empty_like(hidden)
+    xx = torch.empty(n, dtype=torch.float32, device=hidden.device)
+    rms = torch.empty(n, dtype=torch.float32, device=hidden.device) if want_rms else None
+    with torch.cuda.device(hidden.device):
+        _lib.check(lib.t5vq_rmsnorm_sqnorms_f32(_p(hidden), _p(gamma), _p(keep), scale, eps, n, d, _p(x), _p(xx),
+                                                _p(rms), _stream(hidden)), "rmsnorm_sqnorms")
+    return x, xx, rms
+
+
+def rmsnorm_backward(grad_x, hidden, gamma, keep, scale: float, rms, want_grad_gamma: bool = True):
+    """(grad_hidden, grad_gamma) of rmsnorm_sqnorms (t5vq_rmsnorm_backward_f32)."""
+    lib = _lib.load()
+    grad_x = _need(grad_x.contiguous(), "grad_x", ndim=2)
+    _need(hidden, "hidden", ndim=2), _need(gamma, "gamma", ndim=1), _need(rms, "rms", ndim=1)
+    n, d = hidden.shape
+    gh = torch.empty_like(hidden)
+    gg = ws = None
+    if want_grad_gamma:
+        gg = torch.empty(d, dtype=torch.float32, device=hidden.device)
+        ws = torch.empty(int(lib.t5vq_rmsnorm_backward_blocks(n)) * d, dtype=torch.float32, device=hidden.device)
+    with torch.cuda.device(hidden.device):
+        _lib.check(lib.t5vq_rmsnorm_backward_f32(_p(grad_x), _p(hidden), _p(gamma), _p(keep), scale, _p(rms), n, d,
+                                                 _p(gh), _p(gg), _p(ws), _stream(hidden)), "rmsnorm_backward")
+    return gh, gg
 
 
 def reduce_partials(partials, out):

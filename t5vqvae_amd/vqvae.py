@@ -27,7 +27,7 @@ from . import ops
 
 class _Plan:
     """Per-call configuration handed to the autograd function (plain Python, no tensors)."""
-    __slots__ = ("ema", "training", "cc", "decay", "eps", "loss", "batch", "group", "world_tokens", "module")
+    __slots__ = ("ema", "training", "cc", "decay", "eps", "loss", "batch", "group", "world_tokens", "module", "xx")
 
 
 def _scalar_of(buf: torch.Tensor, i: int) -> torch.Tensor:
@@ -145,7 +145,7 @@ class _QuantizerBase(nn.Module):
                              embed_sum=embed_sum, loss_partial=partial)
             ops.reduce_partials(partial, loss_sum)
         else:                                                    # the whole forward behind one host call
-            ops.vq_forward(x, w, ranges, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+            ops.vq_forward(x, w, ranges, plan.loss, xx=plan.xx, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
                            embed_sum=embed_sum, loss_sum=loss_sum)
 
         n_total = n
@@ -167,10 +167,13 @@ class _QuantizerBase(nn.Module):
         return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q,
                 "dims": (n_total, d, k, batch)}
 
-    def forward(self, inputs, srl=None):
+    def forward(self, inputs, srl=None, _xx=None):
+        """``_xx`` (not part of the reference interface): |x_i|^2 [N] if the producer of ``inputs`` already has them
+        (t5vqvae_amd.encoder_tail); they must be the row norms of exactly this tensor."""
         self._check_loss_name()
         flat, ranges = self._flatten(inputs, srl)
         plan = _Plan()
+        plan.xx = _xx
         plan.ema, plan.training = self._is_ema, self.training
         plan.cc = float(self._commitment_cost)
         plan.decay = float(getattr(self, "_decay", 0.0))

@@ -107,9 +107,10 @@ def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=Non
         loss_partial.copy_(pad.view(-1, 64).sum(1))
 
 
-def vq_forward(x, w, ranges, loss, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
+def vq_forward(x, w, ranges, loss, *, xx=None, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
                loss_sum=None):
-    xx, ee = row_sqnorms(x, w)
+    xx_, ee = row_sqnorms(x, w)
+    xx = xx_ if xx is None else xx
     keys = dist_argmin(x, w, xx, ee, ranges)
     partial = torch.empty(gather_blocks(x.shape[0])) if loss_sum is not None else None
     gather_stats(x, w, keys, loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts, embed_sum=embed_sum,
@@ -124,6 +125,23 @@ def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens, 
                 one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, 1 if update else 0, scalars)
     if update:
         ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay)
+
+
+def rmsnorm_sqnorms(hidden, gamma, keep, scale, eps, want_rms=True):
+    r = torch.sqrt((hidden * hidden).mean(-1, keepdim=True) + eps)
+    x = gamma * (hidden / r)
+    if keep is not None:
+        x = torch.where(keep.bool(), x * torch.tensor(scale, dtype=torch.float32), torch.zeros_like(x))
+    return x, (x * x).sum(1), (r.squeeze(1) if want_rms else None)
+
+
+def rmsnorm_backward(grad_x, hidden, gamma, keep, scale, rms, want_grad_gamma=True):
+    gy = grad_x if keep is None else torch.where(keep.bool(), grad_x * scale, torch.zeros_like(grad_x))
+    r = rms.unsqueeze(1)
+    a = gy * gamma
+    gh = a / r - hidden * ((a * hidden).sum(1, keepdim=True) / (hidden.shape[1] * r ** 3))
+    gg = (gy * hidden / r).sum(0) if want_grad_gamma else None
+    return gh, gg
 
 
 def reduce_partials(partials, out):

@@ -170,3 +170,40 @@ def test_token_sharded_equals_single_process_gloo():
                                             ([(0, 50), (50, 200), (120, 256), (3, 5)], True)])  # straddling
 def test_code_sharded_equals_single_process_gloo(roles, training):
     _run(_code_sharded_worker, roles, training)
+
+
+def test_encoder_tail_host_logic_and_autograd(monkeypatch):
+    """EncoderTailVQ over the CPU stand-in kernels: forward == vq(oracle tail), gradients of hidden states and of
+    the norm weight == torch autograd through the oracle's restatement of the tail (modeling_t5.py:191-207,864-865)."""
+    import fake_ops
+    from oracle import vq_oracle as vo
+    from t5vqvae_amd import vqvae as hv, encoder_tail as et
+    monkeypatch.setattr(hv, "ops", fake_ops)
+    monkeypatch.setattr(et, "ops", fake_ops)
+    torch.manual_seed(0)
+    b, s_, d, k = 3, 20, 32, 50
+    vq = hv.VectorQuantizerEMA(k, d, 0.25, decay=0.99)
+    vq.encodings = "indices"
+    tail = et.EncoderTailVQ(vq, hidden_size=d, dropout_rate=0.1)
+    with torch.no_grad():
+        tail.weight.copy_(torch.rand(d) + 0.5)
+    h = torch.randn(b, s_, d, requires_grad=True)
+    keep = (torch.rand(b, s_, d) > 0.1).to(torch.uint8)
+    w0 = vq._embedding.weight.detach().clone()
+    loss, q, ppl, idx = tail(h, keep_mask=keep)
+    gq = torch.randn_like(q)
+    (loss * 1.3 + (q * gq).sum()).backward()
+
+    h2 = h.detach().clone().requires_grad_(True)
+    g2 = tail.weight.detach().clone().requires_grad_(True)
+    x2 = vo.encoder_tail(h2, g2, 1e-6, keep, 0.1)
+    st = vo.VQState(w0, w0.clone(), torch.zeros(k))
+    o = vo.algorithmic_forward(st, x2.detach(), ema=True, training=True, commitment_cost=0.25)
+    assert torch.equal(idx.squeeze(1), o.indices)
+    qraw = w0[o.indices].view_as(x2)
+    loss2 = 0.25 * ((qraw - x2) ** 2).mean()
+    ste2 = x2 + (qraw - x2).detach()
+    (loss2 * 1.3 + (ste2 * gq).sum()).backward()
+    assert torch.allclose(loss, loss2, rtol=1e-5) and torch.allclose(q, ste2, rtol=1e-5, atol=1e-6)
+    assert (h.grad - h2.grad).norm() / h2.grad.norm() < 1e-5
+    assert (tail.weight.grad - g2.grad).norm() / g2.grad.norm() < 1e-5
