@@ -63,17 +63,18 @@ def distances(flat: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
             - 2 * torch.matmul(flat, weight.t()))
 
 
-def select_codes(d: torch.Tensor, ranges: Optional[torch.Tensor]) -> torch.Tensor:
+def select_codes(d: torch.Tensor, ranges: Optional[torch.Tensor], absolute: bool = False) -> torch.Tensor:
     """First-minimum argmin per row (vqvae/vqvae.py:122).  With per-row [start, end) ranges the
     result is the position INSIDE the slice and is used unchanged as an absolute codebook row --
-    the reference's behaviour at vqvae/vqvae.py:110-119 (no ``+ start``)."""
+    the reference's behaviour at vqvae/vqvae.py:110-119 (no ``+ start``).  ``absolute=True`` is the
+    product's opt-in ``index_mode="absolute"`` (start + argmin), which has no counterpart in the reference."""
     if ranges is None:
         return torch.argmin(d, dim=1)
     r = ranges.reshape(-1, 2)
     k = d.shape[1]
     col = torch.arange(k).unsqueeze(0)
     masked = torch.where((col >= r[:, :1]) & (col < r[:, 1:2]), d, torch.full_like(d, float("inf")))
-    return torch.argmin(masked, dim=1) - r[:, 0]
+    return torch.argmin(masked, dim=1) - (0 if absolute else r[:, 0])
 
 
 def distances_fp64(flat: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

@@ -110,7 +110,7 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
     def _global_keys(self, x, w_local, ranges):
         keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin)
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
-        return keys
+        return self._absolute(keys, ranges)
 
     def _launch(self, x, w_local, ranges, plan, want_diff, want_q):
         ops = vqvae.ops

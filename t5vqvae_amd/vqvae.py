@@ -23,6 +23,9 @@ import torch
 from torch import nn
 
 from . import ops
+from .roles import INDEX_MODES, bucket_by_role
+
+_KEY_NONE = 0x7FFFFFFFFFFFFFFF
 
 
 class _Plan:
@@ -101,6 +104,8 @@ class _QuantizerBase(nn.Module):
             exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
 
     bucket_roles = True          # disentangled mode: visit tokens role by role (see _nearest_keys)
+    index_mode = "reference"     # disentangled mode: "reference" = slice-relative indices used as rows (the
+    #                              reference's behaviour, vqvae/vqvae.py:116-119) | "absolute" = start + argmin
 
     def _nearest_keys(self, x, w, ranges, code_offset=0):
         """Packed (distance, index) keys of the nearest admissible codeword per token.
@@ -109,15 +114,25 @@ class _QuantizerBase(nn.Module):
         argsort of N int64 and one row permutation -- data movement only), so that each 128-token tile of the
         distance kernel carries (mostly) one role and skips every code tile outside it: a grouped codebook then
         costs 2 D sum_r N_r K_r flops instead of 2 D N K.  Keys are scattered back to token order."""
+        if self.index_mode not in INDEX_MODES:
+            raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
         if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
             xx, ee = ops.row_sqnorms(x, w)
-            return ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
-        order = torch.argsort(ranges[:, 0] * (1 << 32) + ranges[:, 1], stable=True)
-        xs = x.index_select(0, order)
-        rs = ranges.index_select(0, order)
-        xx, ee = ops.row_sqnorms(xs, w)
-        ks = ops.dist_argmin(xs, w, xx, ee, rs, code_offset=code_offset)
-        return torch.empty_like(ks).index_copy_(0, order, ks)
+            keys = ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
+        else:
+            order, rs = bucket_by_role(ranges)
+            xs = x.index_select(0, order)
+            xx, ee = ops.row_sqnorms(xs, w)
+            ks = ops.dist_argmin(xs, w, xx, ee, rs, code_offset=code_offset)
+            keys = torch.empty_like(ks).index_copy_(0, order, ks)
+        return keys
+
+    def _absolute(self, keys, ranges):
+        """index_mode "absolute": slice-relative index + start (the index is the key's low word; rows whose range
+        holds no code keep the 'none' key)."""
+        if ranges is None or self.index_mode != "absolute":
+            return keys
+        return torch.where(keys != _KEY_NONE, keys + ranges[:, 0], keys)
 
     def _launch(self, x, w, ranges, plan, want_diff, want_q):
         """Order the kernels of one call (single GPU, or token-sharded when ``plan.group`` is set)."""
@@ -138,8 +153,8 @@ class _QuantizerBase(nn.Module):
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         diff = torch.empty_like(x) if want_diff else None
         q = torch.empty_like(x) if want_q else None
-        if ranges is not None and self.bucket_roles and n >= 1024:
-            keys = self._nearest_keys(x, w, ranges)              # role-bucketed: permute, search, scatter back
+        if ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute"):
+            keys = self._absolute(self._nearest_keys(x, w, ranges), ranges)   # permute, search, scatter back
             partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
             ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
                              embed_sum=embed_sum, loss_partial=partial)
@@ -202,7 +217,7 @@ class _QuantizerBase(nn.Module):
     def _keys(self, inputs, srl):
         flat, ranges = self._flatten(inputs, srl)
         w = self._embedding.weight.detach()
-        return flat, w, self._nearest_keys(flat, w, ranges)
+        return flat, w, self._absolute(self._nearest_keys(flat, w, ranges), ranges)
 
     @torch.no_grad()
     def get_indices(self, inputs, srl=None):

@@ -390,3 +390,29 @@ def test_blended_indices_vs_oracle():
             gap = (bl.gather(1, got) - bl.gather(1, ref)).abs().squeeze(1)[bad]
             band = 1e-6 * ((a.double() ** 2).sum(1) + (b.double() ** 2).sum(1) + (st.weight.double() ** 2).sum(1).max())
             assert bool((gap <= band[bad]).all())
+
+
+@pytest.mark.parametrize("n", [300, 4096])      # below / above the role-bucketing threshold
+def test_index_mode_absolute_vs_oracle(n):
+    """Opt-in index_mode="absolute" (start + slice argmin as the row; no counterpart in the reference) against the
+    oracle evaluated with that convention; the default mode on the same inputs stays slice-relative."""
+    k, d = 1000, 768
+    m, st = make_ema(k, d, 61, disentanglement=True)
+    m.eval()
+    x = synth.normal((1, n, d), 62, 0)
+    srl = synth.role_ranges(n, [(0, 200), (200, 201), (201, 640), (640, 1000)], 63, 0).view(1, n, 2)
+    dist = vo.distances(x.view(-1, d), st.weight)
+    abs_ref = vo.select_codes(dist, srl, absolute=True)
+    rel_ref = vo.select_codes(dist, srl)
+    rel_got = m(x.cuda(), srl.cuda())[3].squeeze(1).cpu()
+    m.index_mode = "absolute"
+    lo, q, ppl, idx = m(x.cuda(), srl.cuda())
+    idx = idx.squeeze(1).cpu()
+    starts = srl.view(-1, 2)[:, 0]
+    assert torch.equal(idx, rel_got + starts)                     # same search, two conventions
+    assert int((idx != abs_ref).sum()) <= 1 and int((rel_got != rel_ref).sum()) <= 1   # near-ties only
+    assert bool(((idx >= starts) & (idx < srl.view(-1, 2)[:, 1])).all())
+    o = vo.algorithmic_forward(st.clone(), x, srl, ema=True, training=False, commitment_cost=0.25,
+                               disentanglement=True, indices=idx)
+    assert rel(q, o.quantized) <= TOL and rel(lo, o.loss) <= TOL and rel(ppl, o.perplexity) <= TOL
+    assert torch.equal(m.get_indices(x.cuda(), srl.cuda()).squeeze(1).cpu(), idx)

@@ -207,3 +207,54 @@ def test_encoder_tail_host_logic_and_autograd(monkeypatch):
     assert torch.allclose(loss, loss2, rtol=1e-5) and torch.allclose(q, ste2, rtol=1e-5, atol=1e-6)
     assert (h.grad - h2.grad).norm() / h2.grad.norm() < 1e-5
     assert (tail.weight.grad - g2.grad).norm() / g2.grad.norm() < 1e-5
+
+
+def test_role_helpers_follow_the_loader():
+    """t5/load_data.py:68-86 and t5/utils.py:22-44 on a hand-worked example."""
+    from t5vqvae_amd import roles
+    dd = {"V": (0, 1000), "ARG0": (1000, 2000), "residual": (2000, 10000)}
+    r = roles.expand_role_ranges(["ARG0", "V", "ARGM-TMP", "ARG0"], [1, 2, 1, 3], dd, 10)
+    assert r.dtype == torch.int64 and r.shape == (10, 2)
+    assert r.tolist() == [[1000, 2000], [0, 1000], [0, 1000], [2000, 10000], [1000, 2000], [1000, 2000], [1000, 2000],
+                          [2000, 10000], [2000, 10000], [2000, 10000]]          # unknown label and padding -> residual
+    with pytest.raises(ValueError):
+        roles.expand_role_ranges(["V"], [1, 2], dd, 10)
+    with pytest.raises(ValueError):
+        roles.expand_role_ranges(["V"], [11], dd, 10)
+    v = roles.role_vocab([["V", "ARG0", "V"], ["ARG1", "V", "ARG0"]])
+    assert v == {"V": 0, "ARG0": 1, "ARG1": 2, "FIX": 3, "PAD": 4}               # most frequent first
+    order, rs = roles.bucket_by_role(r)
+    assert rs[:, 0].tolist() == sorted(r[:, 0].tolist()) and order[:2].tolist() == [1, 2]   # stable
+
+
+def test_index_mode_absolute_host_logic(monkeypatch):
+    """index_mode="absolute": start + slice argmin used as the row, against the oracle with the same convention;
+    the default stays the reference's slice-relative convention."""
+    import fake_ops
+    from oracle import vq_oracle as vo
+    from t5vqvae_amd import vqvae as hv
+    monkeypatch.setattr(hv, "ops", fake_ops)
+    torch.manual_seed(1)
+    n, d, k = 1500, 16, 60
+    m = hv.VectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=True)
+    m.encodings = "indices"
+    m.eval()
+    x = torch.randn(1, n, d)
+    table = torch.tensor([[0, 10], [10, 35], [35, 60]])
+    srl = table[torch.randint(0, 3, (n,))].view(1, n, 2)
+    w = m._embedding.weight.detach().clone()
+    dist = vo.distances(x.view(-1, d), w)
+    rel_idx = vo.select_codes(dist, srl)
+    abs_idx = vo.select_codes(dist, srl, absolute=True)
+    assert torch.equal(abs_idx, rel_idx + srl.view(-1, 2)[:, 0])
+    assert torch.equal(m(x, srl)[3].squeeze(1), rel_idx)
+    m.index_mode = "absolute"
+    lo, q, ppl, idx = m(x, srl)
+    assert torch.equal(idx.squeeze(1), abs_idx)
+    assert torch.equal(m.get_indices(x, srl).squeeze(1), abs_idx)
+    ref = vo.algorithmic_forward(vo.VQState(w, w.clone(), torch.zeros(k)), x, srl, ema=True, training=False,
+                                 commitment_cost=0.25, disentanglement=True, indices=abs_idx)
+    assert torch.allclose(q, ref.quantized, rtol=1e-5, atol=1e-6) and torch.allclose(lo, ref.loss, rtol=1e-5)
+    m.index_mode = "bogus"
+    with pytest.raises(ValueError):
+        m(x, srl)
