@@ -9,7 +9,7 @@ result once more just to form |x|^2.  ``EncoderTailVQ`` does norm + dropout + |x
 returns the gradients of the hidden states and of the norm weight.
 
 A maintainer who wants the fusion replaces ``final_layer_norm`` / ``dropout`` of the encoder stack by identities
-and calls this module where ``self.vqvae(encoding, srl_ids)`` is called (INTEGRATION.md section 5).  The plain
+and calls this module where ``self.vqvae(encoding, srl_ids)`` is called (INTEGRATION.md section 4).  The plain
 drop-in (``VectorQuantizerEMA`` alone) does not need it.
 
 The dropout mask is drawn with torch's generator (``bernoulli_``) and passed to the kernel as a uint8 tensor, or
