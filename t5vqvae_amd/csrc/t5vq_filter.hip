@@ -1,0 +1,532 @@
+// t5vq_filter.hip -- exact nearest-code search by filtering in fp16 and deciding in fp32 (gfx950).
+//
+// The fused fp32 scan (t5vq_kernels.hip) is bound by the fp32 matrix pipe; the fp16 / bf16 pipe is 16x faster.  Here
+// the fp16 pipe only FILTERS: for every token it leaves the few codes that could be the fp32 argmin, and the fp32
+// arithmetic of the scan kernel is then repeated for those codes alone.  The result is the scan kernel's result,
+// bit for bit, ties included.
+//
+//   d(i,k)   = fl(fl(xx_i + ee_k) - 2 dot(i,k)),  dot = the k-ordered fp32 fma chain of the scan kernel
+//   d~(i,k)  = the same expression with dot~ = fp16(x_i) . fp16(e_k) (rows scaled by powers of two) accumulated in fp32 by the MFMA
+//   |d~ - d| <= delta(i,k) = c2 |x_i| |e_k| + r (xx_i + ee_k)          (bound derived in DESIGN.md section 8)
+//   T_i = min_k (d~ + delta)                     >= d(i, k*) for the true argmin k*
+//   candidates {k : d~ - delta <= T_i}           contain k* and every code tied with it
+//   refine: exact d for the candidates in the scan kernel's summation order, packed-key minimum
+// One fp16 pass: every scanner (a fixed subset of a token's codes) keeps its smallest upper bound and its KEEP
+// smallest lower bounds; collect_kernel forms T_i and filters the kept pairs.  A token with more than CAND_MAX
+// candidates, or with a scanner that may have dropped one, is decided by an exact scan of all codes.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "t5vq_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr long long KEY_NONE = 0x7FFFFFFFFFFFFFFFLL;
+constexpr int CAND_MAX = 16;            // candidates kept per token; more -> exact scan of all codes for that token
+constexpr int KEEP = 4;                 // lowest lower bounds each scanner keeps (a scanner = one lane half of one
+                                        // wave of one code split: it sees a fixed subset of the codes of its token)
+constexpr int TOK_TILE = 256, CODE_TILE = 256, THREADS = 512;
+constexpr int BKC = 32;                 // 16-byte-aligned chunk of a row, in 4-byte units = 64 fp16
+constexpr int ROW = BKC + 4;            // LDS row stride (4-byte units): 144 B = 9 x 16 B, conflict-free b128 reads
+constexpr int X_IMG = TOK_TILE * ROW, W_IMG = CODE_TILE * ROW, STAGE = X_IMG + W_IMG;
+constexpr int LDS_BYTES = 2 * STAGE * 4;   // 147,456 B: one workgroup (8 waves) per CU
+constexpr int F4_PER_ROW = BKC / 4, ROWS_PER_PASS = THREADS / F4_PER_ROW, XV = TOK_TILE / ROWS_PER_PASS,
+              WV = CODE_TILE / ROWS_PER_PASS, G = BKC / 8;
+constexpr int TB = 2, CB = 4;           // 32x32 blocks per wave: 64 tokens x 128 codes
+
+__device__ __forceinline__ int order_image(float d) {
+    const int b = __float_as_int(d);
+    return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__device__ __forceinline__ long long pack_key(float d, int idx) {
+    return (static_cast<long long>(order_image(d)) << 32) | static_cast<unsigned int>(idx);
+}
+// ---- preparation: fp16 images of x and w, every row scaled by a power of two so that its largest magnitude lies in
+// [2^14, 2^15): the scaling is exact, rows of any magnitude (dead codes reach 1e6) fit fp16's range, and elements
+// down to 2^-28 of the row maximum keep 11 significant bits.  inv[row] = the inverse factor (a power of two).
+// One wave per row; se[k] = sqrt(ee[k]) for the error bound.
+template <int NCH>
+__global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restrict__ x, long long n_x,
+                                                          _Float16* __restrict__ xh, float* __restrict__ x_inv,
+                                                          const float* __restrict__ w, long long n_w,
+                                                          _Float16* __restrict__ wh, float* __restrict__ w_inv,
+                                                          const float* __restrict__ ee, long long kpad,
+                                                          float* __restrict__ se, int D) {
+    const int lane = threadIdx.x & 63;
+    long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row < kpad && lane == 0) {
+        se[row] = sqrtf(ee[row]);
+        if (row >= n_w) w_inv[row] = 1.0f;
+    }
+    const float* src;
+    _Float16* dst;
+    float* inv;
+    if (row < n_x) {
+        src = x + row * D; dst = xh + row * D; inv = x_inv + row;
+    } else {
+        row -= n_x;
+        if (row >= n_w) return;
+        src = w + row * D; dst = wh + row * D; inv = w_inv + row;
+    }
+    f32x4 v[NCH];
+    float m = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c4 = j * 64 + lane;
+        v[j] = (c4 * 4 < D) ? reinterpret_cast<const f32x4*>(src)[c4] : zero4;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    int e = ((__float_as_int(m) >> 23) & 0xFF) - 127;   // floor(log2 m) for normal m
+    int sexp = 14 - e;
+    if (m == 0.f || e < -100) sexp = 0;                   // all-zero (or denormal) row: no scaling
+    sexp = sexp > 100 ? 100 : (sexp < -100 ? -100 : sexp);
+    const float scale = __int_as_float((sexp + 127) << 23);
+    if (lane == 0) *inv = __int_as_float((127 - sexp) << 23);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c4 = j * 64 + lane;
+        if (c4 * 4 < D) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 o;
+            o.x = static_cast<_Float16>(v[j].x * scale);
+            o.y = static_cast<_Float16>(v[j].y * scale);
+            o.z = static_cast<_Float16>(v[j].z * scale);
+            o.w = static_cast<_Float16>(v[j].w * scale);
+            reinterpret_cast<f16x4*>(dst)[c4] = o;
+        }
+    }
+}
+
+// per-scanner state of one token: smallest upper bound seen, and the KEEP smallest lower bounds with their codes
+struct Scan {
+    float umin;
+    float kl[KEEP];
+    int kc[KEEP];
+};
+__device__ __forceinline__ void scan_init(Scan& s) {
+    s.umin = __int_as_float(0x7F800000);
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        s.kl[i] = __int_as_float(0x7F800000);
+        s.kc[i] = -1;
+    }
+}
+__device__ __forceinline__ void scan_insert(Scan& s, float l, int c) {  // keeps kl ascending; no-op if l >= kl[KEEP-1]
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const bool lt = l < s.kl[i];
+        const float tl = s.kl[i];
+        const int tc = s.kc[i];
+        s.kl[i] = lt ? l : tl;
+        s.kc[i] = lt ? c : tc;
+        l = lt ? tl : l;
+        c = lt ? tc : c;
+    }
+}
+
+// ---- the fp16 scan.  Workgroup = 8 waves, tile = 256 tokens x 256 codes, K-chunk = 64 fp16; wave (wt, wc) owns
+// tokens [64 wt, +64) x codes [128 wc, +128): 2 x 4 accumulators of v_mfma_f32_32x32x16_f16.  Operand layout as in
+// the fp32 scan kernel (token on the lane, codes in the accumulator registers); a 16-byte LDS fragment holds the
+// 8 fp16 a lane feeds one MFMA (lane (r, h): k = 8h + j of a 16-deep step).  D2 = D / 2 = row length in 4-byte units.
+// Output per scanner and token: umin and the KEEP kept (lower bound, code) pairs, token-minor for coalescing.
+__global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
+    const float* __restrict__ xb, const float* __restrict__ wb, const float* __restrict__ xx,
+    const float* __restrict__ ee, const float* __restrict__ se, const float* __restrict__ x_inv,
+    const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, float c2,
+    float r, float* __restrict__ ubuf, float* __restrict__ lbuf, int* __restrict__ cbuf) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wt = wave & 3, wc = wave >> 2;
+    const int grp = blockIdx.x / (8 * n_splits);
+    const int split = (blockIdx.x / 8) % n_splits;
+    const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
+    if (tok_base >= N) return;
+    const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > n_code_tiles) tile_end = n_code_tiles;
+    const int n_tiles = tile_end - tile_begin;
+    const int n_chunks = D2 / BKC;  // D % 64 == 0 is required by the launcher
+    const int total = n_tiles * n_chunks;
+
+    Scan sc[TB];
+    int tok[TB];
+    float xv[TB], csx[TB], m2[TB];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        scan_init(sc[b]);
+        tok[b] = tok_base + wt * 64 + b * 32 + l31;
+        const int tc = tok[b] < N ? tok[b] : N - 1;
+        xv[b] = xx[tc];
+        csx[b] = c2 * sqrtf(xv[b]);
+        m2[b] = -2.0f * x_inv[tc];   // -2 and the token row's inverse scale: exact (power of two)
+    }
+
+    if (n_tiles > 0) {
+        const int s_row = tid / F4_PER_ROW, s_col = (tid % F4_PER_ROW) * 4;
+        const float* xrow[XV];
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            int t = tok_base + s_row + ROWS_PER_PASS * j;
+            if (t > N - 1) t = N - 1;
+            xrow[j] = xb + static_cast<size_t>(t) * D2 + s_col;
+        }
+        f32x4 sxv[XV], swv[WV];
+        auto load_stage = [&](int ct, int kc) {
+#pragma unroll
+            for (int j = 0; j < XV; ++j) sxv[j] = *reinterpret_cast<const f32x4*>(xrow[j] + kc * BKC);
+#pragma unroll
+            for (int j = 0; j < WV; ++j) {
+                int c = (tile_begin + ct) * CODE_TILE + s_row + ROWS_PER_PASS * j;
+                if (c > K - 1) c = K - 1;
+                swv[j] = *reinterpret_cast<const f32x4*>(wb + static_cast<size_t>(c) * D2 + s_col + kc * BKC);
+            }
+        };
+        auto store_stage = [&](int buf) {
+            float* xs = lds + buf * STAGE;
+            float* ws = xs + X_IMG;
+#pragma unroll
+            for (int j = 0; j < XV; ++j)
+                *reinterpret_cast<f32x4*>(xs + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = sxv[j];
+#pragma unroll
+            for (int j = 0; j < WV; ++j)
+                *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
+        };
+
+        load_stage(0, 0);
+        store_stage(0);
+        __syncthreads();
+        int it = 0;
+        for (int ct = 0; ct < n_tiles; ++ct) {
+            f32x16 acc[TB][CB];
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int t = 0; t < CB; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[b][t][q] = 0.f;
+            for (int kc = 0; kc < n_chunks; ++kc, ++it) {
+                const bool has_next = it + 1 < total;
+                const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW + 4 * h;
+                const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW + 4 * h;
+                if (has_next) {
+                    int nkc = kc + 1, nct = ct;
+                    if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
+                    load_stage(nct, nkc);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    f16x8 bf[TB], af[CB];
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        bf[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(xs + b * 32 * ROW + 8 * g));
+#pragma unroll
+                    for (int t = 0; t < CB; ++t)
+                        af[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + 8 * g));
+#pragma unroll
+                    for (int t = 0; t < CB; ++t)
+#pragma unroll
+                        for (int b = 0; b < TB; ++b)
+                            acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[b], acc[b][t], 0, 0, 0);
+                }
+                if (has_next) store_stage((it + 1) & 1);
+                __syncthreads();
+            }
+            // epilogue: d~ = fl(fl(xx + ee) - 2 dot~), delta = c2 |x| |e| + r (xx + ee); U = d~ + delta, L = d~ - delta
+            const int code0 = (tile_begin + ct) * CODE_TILE + wc * 128 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < CB; ++t) {
+                if (code0 + t * 32 >= kpad) break;   // |e|^2 is padded to 128 codes, the tile spans 256
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cb = code0 + t * 32 + 8 * g4;
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(ee + cb);
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(se + cb);
+                    const f32x4 i4 = *reinterpret_cast<const f32x4*>(w_inv + cb);
+#pragma unroll
+                    for (int b = 0; b < TB; ++b) {
+                        float lo[4];
+                        float lmin = __int_as_float(0x7F800000);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float s = xv[b] + e4[c];
+                            const float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);   // -2 dot~, rescaled exactly
+                            const float delta = fmaf(csx[b], s4[c], r * s);
+                            sc[b].umin = fminf(sc[b].umin, d + delta);   // padded codes: +inf
+                            lo[c] = d - delta;                           // padded codes: inf - inf = NaN
+                            lmin = fminf(lmin, lo[c]);                   // fminf drops the NaN
+                        }
+                        // only a lower bound below both the smallest upper bound so far and the worst kept one matters
+                        if (__any(lmin <= sc[b].umin && lmin < sc[b].kl[KEEP - 1])) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (lo[c] <= sc[b].umin) scan_insert(sc[b], lo[c], cb + c);   // NaN compares false
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int scanner = (split * 2 + wc) * 2 + h;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+        if (tok[b] < N) {
+            ubuf[static_cast<size_t>(scanner) * N + tok[b]] = sc[b].umin;
+#pragma unroll
+            for (int i = 0; i < KEEP; ++i) {
+                lbuf[(static_cast<size_t>(scanner) * KEEP + i) * N + tok[b]] = sc[b].kl[i];
+                cbuf[(static_cast<size_t>(scanner) * KEEP + i) * N + tok[b]] = sc[b].kc[i];
+            }
+        }
+    }
+}
+
+// ---- collect: T_i = min over scanners of umin; candidates = kept pairs with lower bound <= T_i.  A scanner whose
+// KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
+__global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
+                                                      const int* __restrict__ cbuf, int N, int n_scanners,
+                                                      int* __restrict__ cnt, int* __restrict__ cand) {
+    const int tok = blockIdx.x * 256 + threadIdx.x;
+    if (tok >= N) return;
+    float T = __int_as_float(0x7F800000);
+    for (int s = 0; s < n_scanners; ++s) T = fminf(T, ubuf[static_cast<size_t>(s) * N + tok]);
+    int n = 0;
+    bool overflow = false;
+    for (int s = 0; s < n_scanners; ++s) {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const float l = lbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
+            const int c = cbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
+            if (c >= 0 && l <= T) {
+                ++q;
+                if (n < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + n] = c;
+                ++n;
+            }
+        }
+        overflow |= q == KEEP;
+    }
+    cnt[tok] = (overflow || n > CAND_MAX) ? CAND_MAX + 1 : n;
+}
+
+// exact fp32 distance of one (token, code) pair in the scan kernel's arithmetic: k-ordered fma chain, within each
+// group of 8 the order 0,4,1,5,2,6,3,7 (what its MFMA operand layout feeds the matrix pipe), then fl(fl(xx+ee) - 2 dot)
+__device__ __forceinline__ float exact_distance(const float* __restrict__ xr, const float* __restrict__ wr, int D,
+                                                float xxv, float eev) {
+    float dot = 0.f;
+    for (int k = 0; k < D; k += 32) {   // D % 64 == 0; the 16 loads of an iteration are issued before its fma chain
+        f32x4 xq[8], wq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xq[i] = *reinterpret_cast<const f32x4*>(xr + k + 4 * i);
+            wq[i] = *reinterpret_cast<const f32x4*>(wr + k + 4 * i);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 x0 = xq[2 * g], x1 = xq[2 * g + 1], w0 = wq[2 * g], w1 = wq[2 * g + 1];
+            dot = fmaf(w0.x, x0.x, dot);
+            dot = fmaf(w1.x, x1.x, dot);
+            dot = fmaf(w0.y, x0.y, dot);
+            dot = fmaf(w1.y, x1.y, dot);
+            dot = fmaf(w0.z, x0.z, dot);
+            dot = fmaf(w1.z, x1.z, dot);
+            dot = fmaf(w0.w, x0.w, dot);
+            dot = fmaf(w1.w, x1.w, dot);
+        }
+    }
+    return fmaf(-2.0f, dot, xxv + eev);
+}
+
+// ---- refine: one lane per (token, candidate slot); a token's CAND_MAX lanes sit side by side ------------------
+__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ xx, const float* __restrict__ ee,
+                                                     int N, int K, int D, const int* __restrict__ cnt,
+                                                     const int* __restrict__ cand, long long* __restrict__ keys) {
+    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    const int tok = static_cast<int>(gid / CAND_MAX);
+    const int slot = static_cast<int>(gid % CAND_MAX);
+    long long key = KEY_NONE;
+    int n = 0;
+    if (tok < N) {
+        n = cnt[tok];
+        if (n <= CAND_MAX && slot < n) {
+            const int code = cand[static_cast<size_t>(tok) * CAND_MAX + slot];
+            key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D, w + static_cast<size_t>(code) * D, D,
+                                          xx[tok], ee[code]), code);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < CAND_MAX; o <<= 1) {
+        const long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if (tok < N && slot == 0 && n <= CAND_MAX) keys[tok] = key;
+}
+
+// ---- tokens whose candidate list overflowed: exact scan of every code, one workgroup per token ----------------
+__global__ __launch_bounds__(256) void overflow_scan_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ xx, const float* __restrict__ ee,
+                                                            int N, int K, int D, const int* __restrict__ cnt,
+                                                            long long* __restrict__ keys, int* __restrict__ n_overflow) {
+    __shared__ long long s_best[4];
+    for (int tok = blockIdx.x; tok < N; tok += gridDim.x) {
+        if (cnt[tok] <= CAND_MAX) continue;   // uniform over the workgroup
+        long long best = KEY_NONE;
+        for (int code = threadIdx.x; code < K; code += 256) {
+            const long long key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D,
+                                                          w + static_cast<size_t>(code) * D, D, xx[tok], ee[code]), code);
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long b = s_best[0];
+            for (int i = 1; i < 4; ++i) b = s_best[i] < b ? s_best[i] : b;
+            keys[tok] = b;
+            if (n_overflow) atomicAdd(n_overflow, 1);
+        }
+    }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+struct FilterWorkspace {
+    int64_t xb, wb, se, xinv, winv, ubuf, lbuf, cbuf, cnt, cand, total;
+    FilterWorkspace(int64_t N, int64_t K, int64_t D, int64_t scanners) {
+        xb = 0;
+        wb = align_up(xb + 2 * N * D, 256);
+        se = align_up(wb + 2 * K * D, 256);
+        xinv = align_up(se + 4 * t5vq_padded_codes(K), 256);
+        winv = align_up(xinv + 4 * N, 256);
+        ubuf = align_up(winv + 4 * t5vq_padded_codes(K), 256);
+        lbuf = align_up(ubuf + 4 * N * scanners, 256);
+        cbuf = align_up(lbuf + 4 * N * scanners * KEEP, 256);
+        cnt = align_up(cbuf + 4 * N * scanners * KEEP, 256);
+        cand = align_up(cnt + 4 * N, 256);
+        total = align_up(cand + 4 * N * CAND_MAX, 256);
+    }
+};
+constexpr int MAX_SPLITS = 8;
+
+// code splits (ids 8 apart = one XCD): fill 256 workgroup slots, at most MAX_SPLITS, at least 2 code tiles each
+int64_t plan_filter_splits(int64_t N, int64_t K) {
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    int64_t splits = 1;
+    while (splits < MAX_SPLITS && tok_tiles * splits < 256 && code_tiles / (splits * 2) >= 2) splits *= 2;
+    return splits;
+}
+bool attr_done[64] = {};
+
+}  // namespace
+
+extern "C" {
+
+int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
+    if (N < 0 || K < 0 || D < 0) return 0;
+    return FilterWorkspace(N, K, D, 4 * MAX_SPLITS).total;
+}
+
+int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
+                                  int64_t K, int64_t D, void* workspace, int64_t workspace_bytes, int64_t* keys,
+                                  int32_t* n_overflow, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
+    T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
+    T5VQ_I_REQUIRE(D >= 64 && D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, 64 <= D <= 4096");
+    T5VQ_I_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0 &&
+                       (reinterpret_cast<uintptr_t>(ee) & 15u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+                   "x, w, ee must be 16-byte aligned and the workspace 256-byte aligned");
+    const int64_t splits = plan_filter_splits(N, K);
+    const int64_t scanners = 4 * splits;
+    const FilterWorkspace ws(N, K, D, scanners);
+    T5VQ_I_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_filter_workspace_bytes(N, K, D)");
+    int dev = 0;
+    T5VQ_I_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done[dev] = true;
+    }
+    char* base = static_cast<char*>(workspace);
+    _Float16* xb = reinterpret_cast<_Float16*>(base + ws.xb);
+    _Float16* wb = reinterpret_cast<_Float16*>(base + ws.wb);
+    float* se = reinterpret_cast<float*>(base + ws.se);
+    float* x_inv = reinterpret_cast<float*>(base + ws.xinv);
+    float* w_inv = reinterpret_cast<float*>(base + ws.winv);
+    float* ubuf = reinterpret_cast<float*>(base + ws.ubuf);
+    float* lbuf = reinterpret_cast<float*>(base + ws.lbuf);
+    int* cbuf = reinterpret_cast<int*>(base + ws.cbuf);
+    int* cnt = reinterpret_cast<int*>(base + ws.cnt);
+    int* cand = reinterpret_cast<int*>(base + ws.cand);
+    const int64_t kpad = t5vq_padded_codes(K);
+
+    {
+        const int64_t rows = N + kpad;   // x rows, then w rows and the |e|^2 padding
+        const dim3 pgrid(static_cast<unsigned>((rows + 3) / 4));
+        const int nch = static_cast<int>((D + 255) / 256);
+#define T5VQ_PREP(NCH_)                                                                                          \
+    hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
+                       x_inv, w, static_cast<long long>(K), wb, w_inv, ee, static_cast<long long>(kpad), se,     \
+                       static_cast<int>(D))
+        if (nch <= 1) T5VQ_PREP(1);
+        else if (nch <= 2) T5VQ_PREP(2);
+        else if (nch <= 3) T5VQ_PREP(3);
+        else if (nch <= 4) T5VQ_PREP(4);
+        else if (nch <= 8) T5VQ_PREP(8);
+        else T5VQ_PREP(16);
+#undef T5VQ_PREP
+    }
+    T5VQ_I_CHECK_HIP(hipGetLastError());
+
+    // error coefficient of the fp16 dot product against the fp32 chain, relative to |x| |e|:
+    // two operand roundings (u = 2^-11 each; elements below 2^-28 of their row maximum fall into fp16's denormals,
+    // absolute error 2^-39 of the maximum: the sqrt(D) 2^-37 term), the matrix pipe's fp32 accumulation of the exact
+    // products (<= D 2^-22), the chain's own rounding (<= 1.01 D 2^-24); doubled because the distance carries 2 dot;
+    // 2 % margin for the fp32 evaluation of the bound itself.  r covers the roundings of the distance expression and
+    // of the bound's sums.
+    const double u = 1.0 / 2048.0;
+    const double c_dot = (2 * u + u * u) + sqrt(static_cast<double>(D)) * (1.0 / 137438953472.0) +
+                         D * (1.0 / 4194304.0) + 1.01 * D * (1.0 / 16777216.0);
+    const float c2 = static_cast<float>(2.0 * c_dot * 1.02);
+    const float r = 1.0f / 1048576.0f;  // 2^-20
+
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
+    const dim3 grid(static_cast<unsigned>((tok_tiles + 7) / 8 * 8 * splits));
+    hipLaunchKernelGGL(filter_f16_kernel, grid, dim3(THREADS), LDS_BYTES, stream, reinterpret_cast<const float*>(xb),
+                       reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv, static_cast<int>(N),
+                       static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2), static_cast<int>(splits), static_cast<int>(tiles_per_split), c2, r, ubuf,
+                       lbuf, cbuf);
+    T5VQ_I_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
+                       cbuf, static_cast<int>(N), static_cast<int>(scanners), cnt, cand);
+    T5VQ_I_CHECK_HIP(hipGetLastError());
+    if (n_overflow) T5VQ_I_CHECK_HIP(hipMemsetAsync(n_overflow, 0, 4, stream));
+    hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
+                       xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), cnt, cand,
+                       reinterpret_cast<long long*>(keys));
+    T5VQ_I_CHECK_HIP(hipGetLastError());
+    const int64_t ob = N < 2048 ? N : 2048;
+    hipLaunchKernelGGL(overflow_scan_kernel, dim3(static_cast<unsigned>(ob)), dim3(256), 0, stream, x, w, xx, ee,
+                       static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), cnt,
+                       reinterpret_cast<long long*>(keys), n_overflow);
+    T5VQ_I_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+}  // extern "C"

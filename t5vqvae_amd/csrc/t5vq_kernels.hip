@@ -31,6 +31,11 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
     return code;
 }
 
+}  // namespace
+// error hook shared with the other translation units of the library (t5vq_internal.h)
+int t5vq_internal_fail(int code, const char* fmt, const char* a, const char* b) { return fail(code, fmt, a, b); }
+namespace {
+
 #define T5VQ_CHECK_HIP(expr)                                                         \
     do {                                                                             \
         hipError_t e_ = (expr);                                                      \

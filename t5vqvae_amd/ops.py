@@ -88,6 +88,30 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
     return keys
 
 
+def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False):
+    """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in bf16 and deciding in fp32
+    (t5vq_dist_argmin_filtered_f32).  Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d or xx.shape[0] != n or ee.shape[0] != padded_codes(k):
+        raise RuntimeError("dist_argmin_filtered: inconsistent shapes")
+    if d % 64:
+        raise RuntimeError("the filtered search needs D % 64 == 0")
+    if keys is None:
+        keys = torch.empty(n, dtype=torch.int64, device=x.device)
+    else:
+        _need(keys, "keys", torch.int64, 1)
+    nbytes = int(lib.t5vq_filter_workspace_bytes(n, k, d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, _p(ws), nbytes, _p(keys),
+                                                     _p(ovf), _stream(x)), "dist_argmin_filtered")
+    return (keys, ovf) if want_overflow else keys
+
+
 def unpack_keys(keys, want_idx=True, want_dmin=False):
     lib = _lib.load()
     _need(keys, "keys", torch.int64, 1)
