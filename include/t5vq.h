@@ -154,18 +154,22 @@ int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out,
  * reference discards it. */
 int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream);
 
-/* ---- The same search, filtered in bf16 and decided in fp32 (no reference counterpart: an implementation choice) --
- * keys[i] are bit-identical to t5vq_dist_argmin_f32(range = NULL, code_offset = 0, merge = 0): a bf16 MFMA pass
+/* ---- The same search, filtered in fp16 and decided in fp32 (no reference counterpart: an implementation choice) --
+ * keys[i] are bit-identical to t5vq_dist_argmin_f32(range = NULL, code_offset = 0, merge = 0): an fp16 MFMA pass
  * bounds every distance from both sides with a proven error bound, a second pass lists per token the codes whose
  * lower bound does not exceed the smallest upper bound (the fp32 argmin and everything tied with it are among them),
  * and the fp32 distance expression of t5vq_dist_argmin_f32 -- same summation order -- is evaluated for those codes
- * only.  Tokens with more than 8 such codes are decided by an exact scan of all codes.  Needs D % 64 == 0.
- * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (bf16 images of x and w, bounds,
- * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the exact scan. */
+ * only.  Tokens the filter cannot settle (more than 16 such codes) are decided by the fp32 scan kernel run on those
+ * tokens alone.  Needs D % 64 == 0.
+ * exact_keys != 0: keys are bit-identical to t5vq_dist_argmin_f32's.  exact_keys == 0: the INDEX word is identical;
+ * for a token with a single candidate the distance word holds an upper bound instead of the distance (its fp32
+ * evaluation is skipped) -- enough for every consumer that only gathers by index.
+ * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (fp16 images of x and w, bounds,
+ * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan. */
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D);
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
-                                  int64_t K, int64_t D, void* workspace, int64_t workspace_bytes, int64_t* keys,
-                                  int32_t* n_overflow, t5vq_stream_t stream);
+                                  int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
+                                  int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream);
 
 /* ---- Evaluation-side searches (callers of the path in evaluate_vqvae.py) ----------------
  *

@@ -13,7 +13,7 @@
 //   refine: exact d for the candidates in the scan kernel's summation order, packed-key minimum
 // One fp16 pass: every scanner (a fixed subset of a token's codes) keeps its smallest upper bound and its KEEP
 // smallest lower bounds; collect_kernel forms T_i and filters the kept pairs.  A token with more than CAND_MAX
-// candidates, or with a scanner that may have dropped one, is decided by an exact scan of all codes.
+// candidates, or with a scanner that may have dropped one, is decided by the fp32 scan kernel run on those tokens only.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           const float* __restrict__ w, long long n_w,
                                                           _Float16* __restrict__ wh, float* __restrict__ w_inv,
                                                           const float* __restrict__ ee, long long kpad,
-                                                          float* __restrict__ se, int D) {
+                                                          float* __restrict__ se, int D, int* __restrict__ n_list) {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_list = 0;
     long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row < kpad && lane == 0) {
         se[row] = sqrtf(ee[row]);
@@ -293,12 +294,14 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 // KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int n_scanners,
-                                                      int* __restrict__ cnt, int* __restrict__ cand) {
+                                                      int exact_keys, int* __restrict__ cnt, int* __restrict__ cand,
+                                                      long long* __restrict__ keys, int* __restrict__ tok_list,
+                                                      int* __restrict__ n_list) {
     const int tok = blockIdx.x * 256 + threadIdx.x;
     if (tok >= N) return;
     float T = __int_as_float(0x7F800000);
     for (int s = 0; s < n_scanners; ++s) T = fminf(T, ubuf[static_cast<size_t>(s) * N + tok]);
-    int n = 0;
+    int n = 0, first = -1;
     bool overflow = false;
     for (int s = 0; s < n_scanners; ++s) {
         int q = 0;
@@ -308,13 +311,23 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
             const int c = cbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
             if (c >= 0 && l <= T) {
                 ++q;
+                if (n == 0) first = c;
                 if (n < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + n] = c;
                 ++n;
             }
         }
         overflow |= q == KEEP;
     }
-    cnt[tok] = (overflow || n > CAND_MAX) ? CAND_MAX + 1 : n;
+    if (overflow || n > CAND_MAX || n == 0) {   // n == 0 cannot happen for finite inputs; NaN rows take the scan too
+        keys[tok] = KEY_NONE;                   // the listed scan merges into it with atomicMin
+        tok_list[atomicAdd(n_list, 1)] = tok;
+        cnt[tok] = 0;
+    } else if (n == 1 && !exact_keys) {         // the index is decided; T_i (an upper bound of its distance) fills
+        keys[tok] = pack_key(T, first);         // the key's distance word
+        cnt[tok] = 0;
+    } else {
+        cnt[tok] = n;
+    }
 }
 
 // exact fp32 distance of one (token, code) pair in the scan kernel's arithmetic: k-ordered fma chain, within each
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x
     int n = 0;
     if (tok < N) {
         n = cnt[tok];
-        if (n <= CAND_MAX && slot < n) {
+        if (slot < n) {
             const int code = cand[static_cast<size_t>(tok) * CAND_MAX + slot];
             key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D, w + static_cast<size_t>(code) * D, D,
                                           xx[tok], ee[code]), code);
@@ -368,43 +381,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x
         const long long other = __shfl_xor(key, o);
         key = other < key ? other : key;
     }
-    if (tok < N && slot == 0 && n <= CAND_MAX) keys[tok] = key;
-}
-
-// ---- tokens whose candidate list overflowed: exact scan of every code, one workgroup per token ----------------
-__global__ __launch_bounds__(256) void overflow_scan_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ xx, const float* __restrict__ ee,
-                                                            int N, int K, int D, const int* __restrict__ cnt,
-                                                            long long* __restrict__ keys, int* __restrict__ n_overflow) {
-    __shared__ long long s_best[4];
-    for (int tok = blockIdx.x; tok < N; tok += gridDim.x) {
-        if (cnt[tok] <= CAND_MAX) continue;   // uniform over the workgroup
-        long long best = KEY_NONE;
-        for (int code = threadIdx.x; code < K; code += 256) {
-            const long long key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D,
-                                                          w + static_cast<size_t>(code) * D, D, xx[tok], ee[code]), code);
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long other = __shfl_xor(best, o);
-            best = other < best ? other : best;
-        }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long b = s_best[0];
-            for (int i = 1; i < 4; ++i) b = s_best[i] < b ? s_best[i] : b;
-            keys[tok] = b;
-            if (n_overflow) atomicAdd(n_overflow, 1);
-        }
-    }
+    if (tok < N && slot == 0 && n > 0) keys[tok] = key;
 }
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 struct FilterWorkspace {
-    int64_t xb, wb, se, xinv, winv, ubuf, lbuf, cbuf, cnt, cand, total;
+    int64_t xb, wb, se, xinv, winv, ubuf, lbuf, cbuf, cnt, cand, list, nlist, total;
     FilterWorkspace(int64_t N, int64_t K, int64_t D, int64_t scanners) {
         xb = 0;
         wb = align_up(xb + 2 * N * D, 256);
@@ -416,7 +398,9 @@ struct FilterWorkspace {
         cbuf = align_up(lbuf + 4 * N * scanners * KEEP, 256);
         cnt = align_up(cbuf + 4 * N * scanners * KEEP, 256);
         cand = align_up(cnt + 4 * N, 256);
-        total = align_up(cand + 4 * N * CAND_MAX, 256);
+        list = align_up(cand + 4 * N * CAND_MAX, 256);
+        nlist = align_up(list + 4 * N, 256);
+        total = align_up(nlist + 64, 256);
     }
 };
 constexpr int MAX_SPLITS = 8;
@@ -441,8 +425,8 @@ int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
 }
 
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
-                                  int64_t K, int64_t D, void* workspace, int64_t workspace_bytes, int64_t* keys,
-                                  int32_t* n_overflow, t5vq_stream_t stream_) {
+                                  int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
+                                  int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
@@ -472,6 +456,8 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* x
     int* cbuf = reinterpret_cast<int*>(base + ws.cbuf);
     int* cnt = reinterpret_cast<int*>(base + ws.cnt);
     int* cand = reinterpret_cast<int*>(base + ws.cand);
+    int* tok_list = reinterpret_cast<int*>(base + ws.list);
+    int* n_list = reinterpret_cast<int*>(base + ws.nlist);
     const int64_t kpad = t5vq_padded_codes(K);
 
     {
@@ -481,7 +467,7 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* x
 #define T5VQ_PREP(NCH_)                                                                                          \
     hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
                        x_inv, w, static_cast<long long>(K), wb, w_inv, ee, static_cast<long long>(kpad), se,     \
-                       static_cast<int>(D))
+                       static_cast<int>(D), n_list)
         if (nch <= 1) T5VQ_PREP(1);
         else if (nch <= 2) T5VQ_PREP(2);
         else if (nch <= 3) T5VQ_PREP(3);
@@ -514,18 +500,17 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* x
                        lbuf, cbuf);
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
-                       cbuf, static_cast<int>(N), static_cast<int>(scanners), cnt, cand);
+                       cbuf, static_cast<int>(N), static_cast<int>(scanners), exact_keys, cnt, cand,
+                       reinterpret_cast<long long*>(keys), tok_list, n_list);
     T5VQ_I_CHECK_HIP(hipGetLastError());
-    if (n_overflow) T5VQ_I_CHECK_HIP(hipMemsetAsync(n_overflow, 0, 4, stream));
     hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
                        xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), cnt, cand,
                        reinterpret_cast<long long*>(keys));
     T5VQ_I_CHECK_HIP(hipGetLastError());
-    const int64_t ob = N < 2048 ? N : 2048;
-    hipLaunchKernelGGL(overflow_scan_kernel, dim3(static_cast<unsigned>(ob)), dim3(256), 0, stream, x, w, xx, ee,
-                       static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), cnt,
-                       reinterpret_cast<long long*>(keys), n_overflow);
-    T5VQ_I_CHECK_HIP(hipGetLastError());
+    // tokens the filter could not settle: the fp32 scan kernel itself, on those tokens only
+    const int rc = t5vq_internal_scan_listed(x, w, xx, ee, N, K, D, tok_list, n_list, keys, stream);
+    if (rc != T5VQ_OK) return rc;
+    if (n_overflow) T5VQ_I_CHECK_HIP(hipMemcpyAsync(n_overflow, n_list, 4, hipMemcpyDeviceToDevice, stream));
     return T5VQ_OK;
 }
 

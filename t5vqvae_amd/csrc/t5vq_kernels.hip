@@ -200,12 +200,19 @@ struct Frag {
 
 // BOUNDED (top-k passes): `range` is reinterpreted as one packed key per token and only (distance, code) pairs that
 // order strictly AFTER that key are admissible -- pass j of a top-k search excludes the j best found so far.
-template <class C, bool RANGED, bool WRITE_DIST, bool BOUNDED = false>
+// LISTED (decision scan of the filtered search): only the tokens named in tok_list[0 .. *n_listed) are searched;
+// the grid is sized for N tokens and workgroups beyond the list return at once.
+template <class C, bool RANGED, bool WRITE_DIST, bool BOUNDED = false, bool LISTED = false>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
-    const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
+    const float* __restrict__ ee, const long long* __restrict__ range, int N_all, int K, int D, int n_splits,
     int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys,
-    float* __restrict__ dist) {
+    float* __restrict__ dist, const int* __restrict__ tok_list = nullptr, const int* __restrict__ n_listed = nullptr) {
+    int N = N_all;
+    if (LISTED) {
+        N = *n_listed;
+        if (N > N_all) N = N_all;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE;
 
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     for (int j = 0; j < C::XV; ++j) {
         int t = tok_base + s_row + C::ROWS_PER_PASS * j;
         if (t > N - 1) t = N - 1;
+        if (LISTED) t = tok_list[t];
         xrow[j] = x + static_cast<size_t>(t) * D + s_col;
     }
 
@@ -268,7 +276,8 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
 
     // per-lane token data
     const int tok = tok_base + wave * 32 + l31;
-    const int tok_c = tok < N ? tok : N - 1;
+    int tok_c = tok < N ? tok : N - 1;
+    if (LISTED) tok_c = tok_list[tok_c];   // from here on tok_c is the token's row in x / xx / keys
     const float xv = xx[tok_c];
     long long r_start = 0, r_end = 0;
     if (RANGED) {
@@ -414,9 +423,9 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
             key = pack_key(best, static_cast<int>(gi));
         }
         if (atomic_merge) {
-            if (key != KEY_NONE) atomicMin(keys + tok, key);
+            if (key != KEY_NONE) atomicMin(keys + tok_c, key);
         } else {
-            keys[tok] = key;
+            keys[tok_c] = key;
         }
     }
 }
@@ -1350,6 +1359,8 @@ int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time
 
 thread_local bool t_keys_prefilled = false;  // composite forward: keys already hold KEY_NONE
 thread_local bool t_bound = false;           // top-k pass: the range argument holds one excluded key per token
+thread_local const int* t_tok_list = nullptr;  // decision scan of the filtered search: device list of tokens ...
+thread_local const int* t_n_listed = nullptr;  // ... and its length (device)
 
 template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
@@ -1366,6 +1377,8 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         if (V2) {
             T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, false>),
@@ -1388,10 +1401,11 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
             splits = g_force_splits;
             while (splits > code_tiles) splits /= 2;
         }
+        if (t_tok_list) splits = code_tiles;   // the list is usually short: spread its code tiles over the chip
     }
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int atomic = (splits > 1 || merge) ? 1 : 0;
-    if (!dist && splits > 1 && !merge && !t_keys_prefilled) {
+    if (!dist && splits > 1 && !merge && !t_keys_prefilled && !t_tok_list) {
         hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<long long*>(keys), static_cast<long long>(N));
         T5VQ_CHECK_HIP(hipGetLastError());
@@ -1402,7 +1416,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
 #define T5VQ_DIST_ARGS                                                                                        \
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
-    const bool v2 = V2 && !dist && !t_bound && D % C::BKC == 0;
+    const bool v2 = V2 && !dist && !t_bound && !t_tok_list && D % C::BKC == 0;
     const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
     if (v2 && range && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
@@ -1416,6 +1430,9 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     } else if (v2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
+    } else if (t_tok_list) {  // listed tokens only, one code tile per workgroup, merged with atomicMin
+        hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, 1, kp, dist, t_tok_list, t_n_listed);
     } else if (t_bound) {  // top-k pass: `range` carries one excluded key per token
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp, dist);
@@ -1781,6 +1798,17 @@ int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const fl
         T5VQ_CHECK_HIP(hipGetLastError());
     }
     return T5VQ_OK;
+}
+
+// Internal (t5vq_internal.h): fp32 scan of the tokens in tok_list[0 .. *n_listed) only; their keys must hold KEY_NONE.
+int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
+                              int64_t D, const int* tok_list, const int* n_listed, int64_t* keys, hipStream_t stream) {
+    t_tok_list = tok_list;
+    t_n_listed = n_listed;
+    const int rc = launch_dist_cfg<CfgDefault, false>(x, w, xx, ee, nullptr, N, K, D, 0, 1, keys, nullptr, stream);
+    t_tok_list = nullptr;
+    t_n_listed = nullptr;
+    return rc;
 }
 
 int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,

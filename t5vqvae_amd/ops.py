@@ -88,9 +88,10 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
     return keys
 
 
-def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False):
-    """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in bf16 and deciding in fp32
-    (t5vq_dist_argmin_filtered_f32).  Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``."""
+def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False, exact_keys: bool = True):
+    """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
+    (t5vq_dist_argmin_filtered_f32).  ``exact_keys=False``: only the index word is guaranteed (cheaper).
+    Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
     n, d = x.shape
@@ -107,8 +108,9 @@ def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, _p(ws), nbytes, _p(keys),
-                                                     _p(ovf), _stream(x)), "dist_argmin_filtered")
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, 1 if exact_keys else 0,
+                                                     _p(ws), nbytes, _p(keys), _p(ovf), _stream(x)),
+                   "dist_argmin_filtered")
     return (keys, ovf) if want_overflow else keys
 
 

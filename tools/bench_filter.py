@@ -40,8 +40,12 @@ def main():
             nbad = int((k_scan != k_filt).sum())
             t_scan = timed(lambda: ops.dist_argmin(flat, w, xx, ee))
             t_filt = timed(lambda: ops.dist_argmin_filtered(flat, w, xx, ee))
-            print(f"{name} {regime:8s} keys identical: {same} (differing {nbad}) | overflow tokens {int(ovf)} | "
-                  f"scan {t_scan:9.1f} us | filtered {t_filt:9.1f} us | x{t_scan / t_filt:5.2f}", flush=True)
+            k_idx = ops.dist_argmin_filtered(flat, w, xx, ee, exact_keys=False)
+            same_idx = bool(torch.equal(k_idx & 0xFFFFFFFF, k_scan & 0xFFFFFFFF))
+            t_idx = timed(lambda: ops.dist_argmin_filtered(flat, w, xx, ee, exact_keys=False))
+            print(f"{name} {regime:8s} keys identical: {same} (differing {nbad}), index-only identical: {same_idx} | "
+                  f"overflow tokens {int(ovf)} | scan {t_scan:9.1f} us | filtered {t_filt:9.1f} us "
+                  f"(x{t_scan / t_filt:5.2f}) | index-only {t_idx:9.1f} us (x{t_scan / t_idx:5.2f})", flush=True)
 
 
 if __name__ == "__main__":
