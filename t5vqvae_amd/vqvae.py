@@ -104,10 +104,18 @@ class _QuantizerBase(nn.Module):
             exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
 
     bucket_roles = True          # disentangled mode: visit tokens role by role (see _nearest_keys)
+    # How the nearest code is found.  "scan": fused fp32 MFMA distance + argmin over all codes.  "filter": an fp16
+    # MFMA pass with a proven error bound leaves the few codes that can be the fp32 argmin and the scan's fp32
+    # arithmetic decides among them -- the SAME indices, bit for bit, several times faster on large problems.
+    # "auto": filter when it applies (no role ranges, D % 64 == 0) and pays (N*K >= filter_min_work), with a
+    # back-off to the scan while the filter leaves too many tokens unsettled (degenerate codebooks: all rows equal).
+    search = "auto"
+    filter_min_work = 1 << 24    # N*K below which the scan is faster (C2: 2e6 -> scan; C1: 2.9e7 -> filter)
+    filter_backoff_calls = 32    # calls to stay on the scan after a call with > 1/8 of the tokens unsettled
     index_mode = "reference"     # disentangled mode: "reference" = slice-relative indices used as rows (the
     #                              reference's behaviour, vqvae/vqvae.py:116-119) | "absolute" = start + argmin
 
-    def _nearest_keys(self, x, w, ranges, code_offset=0):
+    def _nearest_keys(self, x, w, ranges, code_offset=0, xx=None, exact_keys=True, use_filter=None):
         """Packed (distance, index) keys of the nearest admissible codeword per token.
 
         Disentangled mode with many tokens: tokens are first bucketed by their [start, end) range (a stable
@@ -117,14 +125,59 @@ class _QuantizerBase(nn.Module):
         if self.index_mode not in INDEX_MODES:
             raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
         if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
-            xx, ee = ops.row_sqnorms(x, w)
-            keys = ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
+            xx, ee = ops.row_sqnorms(x, w) if xx is None else (xx, ops.row_sqnorms(None, w)[1])
+            if use_filter is None:
+                use_filter = self._use_filter(x, w, ranges)
+            if use_filter:
+                keys = self._filtered_keys(x, w, xx, ee, exact_keys or code_offset != 0)
+                if code_offset:
+                    keys = keys + code_offset          # index = low word; indices stay below 2^31: no carry
+            else:
+                keys = ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
         else:
             order, rs = bucket_by_role(ranges)
             xs = x.index_select(0, order)
             xx, ee = ops.row_sqnorms(xs, w)
             ks = ops.dist_argmin(xs, w, xx, ee, rs, code_offset=code_offset)
             keys = torch.empty_like(ks).index_copy_(0, order, ks)
+        return keys
+
+    def _use_filter(self, x, w, ranges) -> bool:
+        if self.search not in ("auto", "scan", "filter"):
+            raise ValueError(f"search must be 'auto', 'scan' or 'filter', got {self.search!r}")
+        n, d = x.shape
+        eligible = ranges is None and d % 64 == 0 and d <= 4096
+        if self.search == "scan" or not eligible:
+            if self.search == "filter":
+                raise RuntimeError("search='filter' needs D % 64 == 0, D <= 4096 and no role ranges")
+            return False
+        if self.search == "filter":
+            return True
+        if n * w.shape[0] < self.filter_min_work:
+            return False
+        st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
+        if st["pending"] is not None and not torch.cuda.is_current_stream_capturing():
+            event, host, n_prev = st["pending"]
+            if event.query():                          # the previous call's count has landed: no host wait
+                st["pending"] = None
+                if int(host[0]) * 8 > n_prev:
+                    st["skip"] = self.filter_backoff_calls
+        if st["skip"] > 0:
+            st["skip"] -= 1
+            return False
+        return True
+
+    def _filtered_keys(self, x, w, xx, ee, exact_keys):
+        keys, ovf = ops.dist_argmin_filtered(x, w, xx, ee, want_overflow=True, exact_keys=exact_keys)
+        if self.search == "auto" and not torch.cuda.is_current_stream_capturing():
+            st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
+            if st["pending"] is None:                  # asynchronous read-back of the unsettled-token count
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(ovf, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+                st["pending"] = (event, host, x.shape[0])
+        self.last_unsettled = ovf
         return keys
 
     def _absolute(self, keys, ranges):
@@ -153,8 +206,11 @@ class _QuantizerBase(nn.Module):
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         diff = torch.empty_like(x) if want_diff else None
         q = torch.empty_like(x) if want_q else None
-        if ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute"):
-            keys = self._absolute(self._nearest_keys(x, w, ranges), ranges)   # permute, search, scatter back
+        use_filter = self._use_filter(x, w, ranges)
+        if (ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute")) or use_filter:
+            # role-bucketed search (permute, search, scatter back) or filtered search, then the fine-grained calls
+            keys = self._absolute(self._nearest_keys(x, w, ranges, xx=plan.xx, exact_keys=False,
+                                                     use_filter=use_filter), ranges)
             partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
             ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
                              embed_sum=embed_sum, loss_partial=partial)

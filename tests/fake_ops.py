@@ -61,6 +61,11 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
     return keys
 
 
+def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow=False, exact_keys=True):
+    out = dist_argmin(x, w, xx, ee, keys=keys)
+    return (out, torch.zeros(1, dtype=torch.int32)) if want_overflow else out
+
+
 def unpack_keys(keys, want_idx=True, want_dmin=False):
     idx = (keys & 0xFFFFFFFF) if want_idx else None
     dmin = None

@@ -1,0 +1,114 @@
+"""Filtered search (fp16 filter + fp32 decision, t5vq_dist_argmin_filtered_f32) against the fp32 scan
+(t5vq_dist_argmin_f32): the keys must be IDENTICAL, bit for bit -- same distances, same tie rule -- on ordinary and
+on degenerate inputs; in index-only mode the index word must be identical."""
+import pytest
+import torch
+
+from oracle import vq_oracle as vo
+from t5vqvae_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def both(x, w, exact=True):
+    from t5vqvae_amd import ops
+    xx, ee = ops.row_sqnorms(x, w)
+    scan = ops.dist_argmin(x, w, xx, ee)
+    filt, ovf = ops.dist_argmin_filtered(x, w, xx, ee, want_overflow=True, exact_keys=exact)
+    return scan, filt, int(ovf)
+
+
+@pytest.mark.parametrize("n,k,d", [(4096, 512, 768), (2880, 10000, 768), (1, 7, 64), (300, 257, 64), (1000, 130, 128),
+                                   (513, 1025, 2048), (65536, 8192, 768), (255, 256, 192), (257, 255, 4096)])
+def test_filtered_keys_identical_to_scan(n, k, d):
+    w = synth.normal((k, d), 71, 0, device="cuda")
+    x = synth.normal((n, d), 72, 0, device="cuda")
+    scan, filt, ovf = both(x, w)
+    assert torch.equal(scan, filt), int((scan != filt).sum())
+    scan, filt, _ = both(x, w, exact=False)
+    assert torch.equal(scan & 0xFFFFFFFF, filt & 0xFFFFFFFF)
+    xc, _ = synth.clustered(n, w, 0.5, 73)
+    scan, filt, ovf = both(xc, w)
+    assert torch.equal(scan, filt) and ovf == 0            # well-separated data: the filter settles every token
+
+
+def test_filtered_search_on_degenerate_codebooks():
+    """Everything the bound has to survive: identical rows (every code is a candidate -> the scan decides), exact
+    duplicates (lowest index), dead codes with huge norms, zero rows, tiny and huge magnitudes, mixed scales."""
+    n, k, d = 1000, 600, 768
+    x = synth.normal((n, d), 74, 0, device="cuda")
+    w = synth.normal((k, d), 75, 0, device="cuda")
+    cases = {}
+    cases["all rows equal"] = (x, w[:1].repeat(k, 1).contiguous())
+    wd = w.clone(); wd[300] = wd[7]; wd[599] = wd[7]; wd[9] = wd[8]
+    cases["duplicates"] = (x, wd)
+    wdead = w.clone(); wdead[::3] *= 4.0e5
+    cases["dead codes"] = (x, wdead)
+    wz = w.clone(); wz[5] = 0; xz = x.clone(); xz[11] = 0
+    cases["zero rows"] = (xz, wz)
+    cases["plain-variant init"] = (x, (synth.normal((k, d), 76, 0, device="cuda") * (1.0 / k)))
+    cases["tiny"] = (x * 1e-18, w * 1e-18)
+    cases["huge"] = (x * 1e15, w * 1e15)
+    ws = w * torch.logspace(-6, 6, k, device="cuda").unsqueeze(1)
+    xs = x * torch.logspace(-3, 3, n, device="cuda").unsqueeze(1)
+    cases["mixed scales"] = (xs.contiguous(), ws.contiguous())
+    wi = w.clone(); wi[:, ::2] *= 1e-9                      # elements far below their row maximum (fp16 denormals)
+    cases["wide rows"] = (x, wi)
+    for name, (xa, wa) in cases.items():
+        scan, filt, ovf = both(xa, wa)
+        assert torch.equal(scan, filt), (name, int((scan != filt).sum()), ovf)
+        scan, filt, _ = both(xa, wa, exact=False)
+        assert torch.equal(scan & 0xFFFFFFFF, filt & 0xFFFFFFFF), name
+    _, _, ovf = both(*cases["all rows equal"])
+    assert ovf == n                                        # nothing can be settled by bounds: all tokens take the scan
+    # and the indices are what the oracle says (ties -> lowest index)
+    scan, filt, _ = both(*cases["duplicates"])
+    ref = vo.select_codes(vo.distances(x.cpu(), wd.cpu()), None)
+    assert int(((filt & 0xFFFFFFFF).cpu() != ref).sum()) <= 1
+
+
+def test_module_filter_and_scan_give_the_same_step():
+    from t5vqvae_amd import VectorQuantizerEMA
+    n, k, d = 8192, 4096, 768
+    w, ew = synth.normal((k, d), 77, 0), synth.normal((k, d), 77, 1)
+    x = synth.normal((8, n // 8, d), 78, 0).cuda()
+
+    def run(search):
+        m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda()
+        with torch.no_grad():
+            m._embedding.weight.copy_(w), m._ema_w.copy_(ew)
+        m.encodings, m.search = "indices", search
+        out = [m(x) for _ in range(2)]
+        return m, out
+    ms, outs = run("scan")
+    mf, outf = run("filter")
+    ma, outa = run("auto")
+    a, b = outs[0], outf[0]                                 # first call: same codebook -> everything identical
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert torch.equal(outs[0][3], outa[0][3])
+    # second call: the codebooks differ in the last bits (embed_sum is summed with float atomics in both modes)
+    a, b = outs[1], outf[1]
+    assert int((a[3] != b[3]).sum()) <= 2
+    assert float((a[0] - b[0]).abs() / a[0].abs()) < 1e-5
+    assert float((ms._ema_cluster_size - mf._ema_cluster_size).abs().max()) <= 1e-6 * float(ms._ema_cluster_size.max())
+    with torch.no_grad():                                   # same codebook again -> identical indices
+        mf._embedding.weight.copy_(ms._embedding.weight)
+    assert torch.equal(ms.get_indices(x), mf.get_indices(x))
+
+
+def test_auto_backs_off_on_a_degenerate_codebook():
+    from t5vqvae_amd import VectorQuantizerEMA
+    n, k, d = 8192, 4096, 768
+    m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda().eval()
+    with torch.no_grad():
+        m._embedding.weight.copy_(synth.normal((1, d), 79, 0).repeat(k, 1))
+    m.encodings = "indices"
+    x = synth.normal((8, n // 8, d), 80, 0).cuda()
+    ref = torch.zeros(n, 1, dtype=torch.int64)              # all rows equal: first minimum = code 0
+    used = []
+    for _ in range(4):
+        idx = m(x)[3]
+        torch.cuda.synchronize()
+        assert torch.equal(idx.cpu(), ref)
+        used.append(m.__dict__["_filter_state"]["skip"])
+    assert used[0] == 0 and max(used) > 0                  # the first call filters, the count comes back, then scan
