@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA, same guide
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -103,6 +104,56 @@ def cpu_baseline(workload, dev, budget_s=20.0):
             "parity": parity}
 
 
+def other_search(mod, x, w, ema_w, cs, args, n, k, d):
+    """The same step with the other search mode (rank 0, single GPU): 'scan' = fused fp32 MFMA distance + argmin;
+    'filter' = fp16 MFMA filter with a proven error bound + the scan's fp32 arithmetic on the surviving codes.
+    Both produce the same indices (checked here on this batch, same initial state)."""
+    from t5vqvae_amd import ops
+    other = "filter" if args.search == "scan" else "scan"
+    if other == "filter" and d % 64:
+        return None
+
+    def reset():
+        with torch.no_grad():
+            mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
+    with torch.no_grad():
+        reset()
+        mod.search = args.search
+        idx_a = mod(x)[3].clone()
+        reset()
+        mod.search = other
+        idx_b = mod(x)[3].clone()
+        for _ in range(max(2, args.warmup)):
+            mod(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mod(x)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        flat = x.reshape(-1, d)
+        wq = mod._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, wq)
+        fn = (lambda: ops.dist_argmin_filtered(flat, wq, xx, ee, exact_keys=False)) if other == "filter" \
+            else (lambda: ops.dist_argmin(flat, wq, xx, ee))
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        s_ms = e0.elapsed_time(e1) / 10
+    mod.search = args.search
+    flops = 2.0 * n * k * d
+    peak = PEAK_F16_MFMA_TFLOPS if other == "filter" else PEAK_FP32_MFMA_TFLOPS
+    return {"search": other, "value": n / (ms * 1e-3), "unit": "vectors/s", "ms_per_step": ms,
+            "indices_identical_to_headline_mode": bool(torch.equal(idx_a, idx_b)),
+            "search_ms": s_ms, "search_algorithmic_tflops": flops / (s_ms * 1e-3) / 1e12,
+            "search_frac_of_pipe_peak": flops / (s_ms * 1e-3) / 1e12 / peak,
+            "pipe": "fp16 MFMA filter (2500 TF) + fp32 decision" if other == "filter" else "fp32 MFMA (157.3 TF)"}
+
+
 def measured_traffic(workload):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json; counters cannot be read from inside this process)."""
@@ -121,6 +172,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--regime", default="uniform", choices=["uniform", "cold"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--search", default="scan", choices=["scan", "filter", "auto"],
+                    help="how the module finds the nearest code for the headline number: 'scan' = the fused fp32 MFMA "
+                         "kernel (the north star's design, default); 'filter'/'auto' = fp16 filter + fp32 decision "
+                         "(identical indices); the other mode is always reported beside it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +204,7 @@ def main():
         mod._ema_w.copy_(ema_w)
         mod._ema_cluster_size.copy_(cs)
     mod.encodings = "indices"
+    mod.search = args.search
     mod.train(update)
     if use_dist:
         shard_tokens(mod)
@@ -182,16 +238,22 @@ def main():
         wq = mod._embedding.weight.detach()
         xx, ee = ops.row_sqnorms(flat, wq)
         keys = torch.empty(n, dtype=torch.int64, device=dev)
+        filt = args.search == "filter" or (args.search == "auto" and d % 64 == 0 and n * k >= mod.filter_min_work)
+        search = (lambda: ops.dist_argmin_filtered(flat, wq, xx, ee, keys=keys, exact_keys=False)) if filt \
+            else (lambda: ops.dist_argmin(flat, wq, xx, ee, keys=keys))
         for _ in range(2):
-            ops.dist_argmin(flat, wq, xx, ee, keys=keys)
+            search()
         reps = 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.dist_argmin(flat, wq, xx, ee, keys=keys)
+            search()
         e1.record()
         torch.cuda.synchronize()
         k_ms = e0.elapsed_time(e1) / reps
+        peak = PEAK_F16_MFMA_TFLOPS if filt else PEAK_FP32_MFMA_TFLOPS
+        kname = "filtered search: filter_f16_kernel + prep/collect/refine" if filt \
+            else "dist_mfma_v2_kernel (fused distance+argmin)"
         flops = 2.0 * n * k * d
         achieved = flops / (k_ms * 1e-3) / 1e12
         result = {
@@ -202,14 +264,17 @@ def main():
             "config": {"workload": desc, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "D": d,
                        "regime": args.regime, "parallelism": f"token-sharded x{world}" if world > 1 else "single GPU",
                        "encodings": "indices (dense one-hot excluded, SURVEY 8b)"},
-            "roofline": {"bound": "mfma", "kernel": "dist_mfma_v2_kernel (fused distance+argmin)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "kernel_ms": k_ms,
-                         "flops_per_launch": flops, "traffic": measured_traffic(args.workload),
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "kernel_ms": k_ms,
+                         "flops_per_launch": flops, "traffic": None if filt else measured_traffic(args.workload),
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
                          "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k},
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
         }
+    if rank == 0 and world == 1:
+        result["config"]["search"] = args.search
+        result["other_search"] = other_search(mod, x, w, ema_w, cs, args, n, k, d)
     if use_dist:
         dist.barrier()
     if rank == 0:
