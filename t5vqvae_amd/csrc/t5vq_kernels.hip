@@ -1357,15 +1357,18 @@ int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time
     return splits;
 }
 
-thread_local bool t_keys_prefilled = false;  // composite forward: keys already hold KEY_NONE
-thread_local bool t_bound = false;           // top-k pass: the range argument holds one excluded key per token
-thread_local const int* t_tok_list = nullptr;  // decision scan of the filtered search: device list of tokens ...
-thread_local const int* t_n_listed = nullptr;  // ... and its length (device)
+// Variations of a distance launch that the plain entry points do not need
+struct DistOpts {
+    bool keys_prefilled = false;     // composite forward: keys already hold KEY_NONE (no fill launch before a split)
+    bool bounded = false;            // top-k pass: the range argument holds one excluded key per token
+    const int* tok_list = nullptr;   // decision scan of the filtered search: device list of the tokens to search ...
+    const int* n_listed = nullptr;   // ... and its length (device)
+};
 
 template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
                            int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
-                           float* dist, hipStream_t stream) {
+                           float* dist, hipStream_t stream, const DistOpts& opts = DistOpts()) {
     static bool attr_done[64] = {false};
     int dev = 0;
     T5VQ_CHECK_HIP(hipGetDevice(&dev));
@@ -1401,11 +1404,11 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
             splits = g_force_splits;
             while (splits > code_tiles) splits /= 2;
         }
-        if (t_tok_list) splits = code_tiles;   // the list is usually short: spread its code tiles over the chip
+        if (opts.tok_list) splits = code_tiles;   // the list is usually short: spread its code tiles over the chip
     }
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int atomic = (splits > 1 || merge) ? 1 : 0;
-    if (!dist && splits > 1 && !merge && !t_keys_prefilled && !t_tok_list) {
+    if (!dist && splits > 1 && !merge && !opts.keys_prefilled && !opts.tok_list) {
         hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<long long*>(keys), static_cast<long long>(N));
         T5VQ_CHECK_HIP(hipGetLastError());
@@ -1416,7 +1419,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
 #define T5VQ_DIST_ARGS                                                                                        \
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
-    const bool v2 = V2 && !dist && !t_bound && !t_tok_list && D % C::BKC == 0;
+    const bool v2 = V2 && !dist && !opts.bounded && !opts.tok_list && D % C::BKC == 0;
     const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
     if (v2 && range && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
@@ -1430,10 +1433,10 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     } else if (v2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
-    } else if (t_tok_list) {  // listed tokens only, one code tile per workgroup, merged with atomicMin
+    } else if (opts.tok_list) {  // listed tokens only, one code tile per workgroup, merged with atomicMin
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
-                           T5VQ_DIST_ARGS, 1, kp, dist, t_tok_list, t_n_listed);
-    } else if (t_bound) {  // top-k pass: `range` carries one excluded key per token
+                           T5VQ_DIST_ARGS, 1, kp, dist, opts.tok_list, opts.n_listed);
+    } else if (opts.bounded) {  // top-k pass: `range` carries one excluded key per token
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp, dist);
     } else if (dist) {
@@ -1453,16 +1456,17 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
 
 int launch_dist(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
                        int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys, float* dist,
-                       hipStream_t stream) {
+                       hipStream_t stream, const DistOpts& opts = DistOpts()) {
     T5VQ_REQUIRE(x && w && xx && ee, "null input");
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
     T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
     T5VQ_REQUIRE(aligned16(x) && aligned16(w) && aligned16(ee), "x, w, ee must be 16-byte aligned");
     T5VQ_REQUIRE(N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 256, "N or K too large");
     T5VQ_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
-#define T5VQ_GO(CFG) return launch_dist_cfg<CFG>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream)
+#define T5VQ_GO(CFG) \
+    return launch_dist_cfg<CFG>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream, opts)
 #define T5VQ_GO2(CFG) \
-    return launch_dist_cfg<CFG, true>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream)
+    return launch_dist_cfg<CFG, true>(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, dist, stream, opts)
     switch (g_dist_variant) {
 #ifdef T5VQ_TUNING
         case 1: T5VQ_GO(Cfg1);
@@ -1803,12 +1807,10 @@ int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const fl
 // Internal (t5vq_internal.h): fp32 scan of the tokens in tok_list[0 .. *n_listed) only; their keys must hold KEY_NONE.
 int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
                               int64_t D, const int* tok_list, const int* n_listed, int64_t* keys, hipStream_t stream) {
-    t_tok_list = tok_list;
-    t_n_listed = n_listed;
-    const int rc = launch_dist_cfg<CfgDefault, false>(x, w, xx, ee, nullptr, N, K, D, 0, 1, keys, nullptr, stream);
-    t_tok_list = nullptr;
-    t_n_listed = nullptr;
-    return rc;
+    DistOpts opts;
+    opts.tok_list = tok_list;
+    opts.n_listed = n_listed;
+    return launch_dist_cfg<CfgDefault, false>(x, w, xx, ee, nullptr, N, K, D, 0, 1, keys, nullptr, stream, opts);
 }
 
 int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
@@ -1819,9 +1821,9 @@ int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const fl
     // pass 0: the plain fused argmin; pass j > 0: the same search restricted to pairs after the pass j-1 winner
     int rc = launch_dist(x, w, xx, ee, nullptr, N, K, D, 0, 0, keys, nullptr, stream);
     for (int64_t j = 1; j < topk && rc == T5VQ_OK; ++j) {
-        t_bound = true;
-        rc = launch_dist(x, w, xx, ee, keys + (j - 1) * N, N, K, D, 0, 0, keys + j * N, nullptr, stream);
-        t_bound = false;
+        DistOpts opts;
+        opts.bounded = true;
+        rc = launch_dist(x, w, xx, ee, keys + (j - 1) * N, N, K, D, 0, 0, keys + j * N, nullptr, stream, opts);
     }
     return rc;
 }
@@ -1884,9 +1886,9 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
     int rc = xx_in ? launch_row_sqnorms(nullptr, 0, nullptr, w, K, ee, D, prep, stream)
                    : launch_row_sqnorms(x, N, reinterpret_cast<float*>(base + ws.xx), w, K, ee, D, prep, stream);
     if (rc != T5VQ_OK) return rc;
-    t_keys_prefilled = true;
-    rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream);
-    t_keys_prefilled = false;
+    DistOpts opts;
+    opts.keys_prefilled = true;
+    rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream, opts);
     if (rc != T5VQ_OK) return rc;
     rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
                        partial, true, stream);
