@@ -112,3 +112,30 @@ def test_auto_backs_off_on_a_degenerate_codebook():
         assert torch.equal(idx.cpu(), ref)
         used.append(m.__dict__["_filter_state"]["skip"])
     assert used[0] == 0 and max(used) > 0                  # the first call filters, the count comes back, then scan
+
+
+def test_filter_tracks_the_scan_through_codebook_collapse():
+    """Cold start -> EMA updates -> dead codes with norms of 1e5..1e6 and a few live ones: at every step the filtered
+    search returns the scan's indices on the module's current codebook."""
+    from t5vqvae_amd import VectorQuantizerEMA, ops
+    n, k, d = 8192, 4096, 768
+    m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda().train()
+    with torch.no_grad():
+        m._embedding.weight.copy_(synth.normal((k, d), 81, 0))
+        m._ema_w.copy_(synth.normal((k, d), 81, 1))
+    m.encodings = "indices"
+    unsettled = []
+    for step in range(10):
+        x = synth.normal((8, n // 8, d), 82, step).cuda()
+        flat = x.view(-1, d)
+        w = m._embedding.weight.detach()
+        xx, ee = ops.row_sqnorms(flat, w)
+        scan = ops.dist_argmin(flat, w, xx, ee)
+        filt, ovf = ops.dist_argmin_filtered(flat, w, xx, ee, want_overflow=True)
+        assert torch.equal(scan, filt), (step, int((scan != filt).sum()))
+        unsettled.append(int(ovf))
+        m.search = "auto"
+        idx = m(x)[3]                                     # training step on the same codebook (pre-update search)
+        assert torch.equal(idx.squeeze(1), scan & 0xFFFFFFFF)
+    assert float(m._embedding.weight.abs().max()) > 1e4    # the codebook did collapse (dead codes blew up)
+    assert max(unsettled) < n // 8
