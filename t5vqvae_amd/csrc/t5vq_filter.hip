@@ -202,8 +202,14 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                 *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
         };
 
+        // Staging pipeline: ONE register set; the tile for step it+1 is written to LDS right AFTER the barrier that
+        // ends step it-1 (its buffer is free from then on) and the loads for step it+2 are re-issued at once, so
+        // every load has a whole step of MFMAs to land.
         load_stage(0, 0);
         store_stage(0);
+        int lct = 0, lkc = 1;                       // (code tile, chunk) of the next stage to load
+        if (lkc == n_chunks) { lkc = 0; lct = 1; }
+        if (total > 1) load_stage(lct, lkc);        // registers now hold step 1
         __syncthreads();
         int it = 0;
         for (int ct = 0; ct < n_tiles; ++ct) {
@@ -215,13 +221,12 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[b][t][q] = 0.f;
             for (int kc = 0; kc < n_chunks; ++kc, ++it) {
-                const bool has_next = it + 1 < total;
                 const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW + 4 * h;
                 const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW + 4 * h;
-                if (has_next) {
-                    int nkc = kc + 1, nct = ct;
-                    if (nkc == n_chunks) { nkc = 0; nct = ct + 1; }
-                    load_stage(nct, nkc);
+                if (it + 1 < total) {
+                    store_stage((it + 1) & 1);      // step it+1, loaded during step it-1
+                    if (++lkc == n_chunks) { lkc = 0; ++lct; }
+                    if (it + 2 < total) load_stage(lct, lkc);
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -238,7 +243,6 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                         for (int b = 0; b < TB; ++b)
                             acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[b], acc[b][t], 0, 0, 0);
                 }
-                if (has_next) store_stage((it + 1) & 1);
                 __syncthreads();
             }
             // epilogue: d~ = fl(fl(xx + ee) - 2 dot~), delta = c2 |x| |e| + r (xx + ee); U = d~ + delta, L = d~ - delta
