@@ -164,10 +164,13 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
  * exact_keys != 0: keys are bit-identical to t5vq_dist_argmin_f32's.  exact_keys == 0: the INDEX word is identical;
  * for a token with a single candidate the distance word holds an upper bound instead of the distance (its fp32
  * evaluation is skipped) -- enough for every consumer that only gathers by index.
+ * compute_norms == 0: xx [N] and ee [padded(K)] are inputs (from t5vq_row_sqnorms_f32 / t5vq_rmsnorm_sqnorms_f32).
+ * compute_norms != 0: they are OUTPUTS: the pass that writes the fp16 images also writes the row norms (bit-identical
+ * to t5vq_row_sqnorms_f32), which saves that launch and its read of x.
  * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (fp16 images of x and w, bounds,
  * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan. */
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D);
-int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
+int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms, int64_t N,
                                   int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream);
 

@@ -50,29 +50,36 @@ __device__ __forceinline__ long long pack_key(float d, int idx) {
 // [2^14, 2^15): the scaling is exact, rows of any magnitude (dead codes reach 1e6) fit fp16's range, and elements
 // down to 2^-28 of the row maximum keep 11 significant bits.  inv[row] = the inverse factor (a power of two).
 // One wave per row; se[k] = sqrt(ee[k]) for the error bound.
-template <int NCH>
+template <int NCH, bool NORMS>
 __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restrict__ x, long long n_x,
                                                           _Float16* __restrict__ xh, float* __restrict__ x_inv,
                                                           const float* __restrict__ w, long long n_w,
                                                           _Float16* __restrict__ wh, float* __restrict__ w_inv,
-                                                          const float* __restrict__ ee, long long kpad,
-                                                          float* __restrict__ se, int D, int* __restrict__ n_list) {
+                                                          float* __restrict__ xx, float* __restrict__ ee,
+                                                          long long kpad, float* __restrict__ se, int D,
+                                                          int* __restrict__ n_list) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_list = 0;
     long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (row < kpad && lane == 0) {
-        se[row] = sqrtf(ee[row]);
-        if (row >= n_w) w_inv[row] = 1.0f;
-    }
     const float* src;
     _Float16* dst;
     float* inv;
-    if (row < n_x) {
-        src = x + row * D; dst = xh + row * D; inv = x_inv + row;
+    float* norm;      // NORMS: where this row's squared norm goes (xx or ee)
+    const bool is_w = row >= n_x;
+    if (!is_w) {
+        src = x + row * D; dst = xh + row * D; inv = x_inv + row; norm = xx + row;
     } else {
         row -= n_x;
-        if (row >= n_w) return;
-        src = w + row * D; dst = wh + row * D; inv = w_inv + row;
+        if (row >= kpad) return;
+        if (row >= n_w) {   // padding of the |e|^2 buffers: +inf, so padded codes can never be candidates
+            if (lane == 0) {
+                if (NORMS) ee[row] = __int_as_float(0x7F800000);
+                se[row] = __int_as_float(0x7F800000);
+                w_inv[row] = 1.0f;
+            }
+            return;
+        }
+        src = w + row * D; dst = wh + row * D; inv = w_inv + row; norm = ee + row;
     }
     f32x4 v[NCH];
     float m = 0.f;
@@ -83,6 +90,22 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         v[j] = (c4 * 4 < D) ? reinterpret_cast<const f32x4*>(src)[c4] : zero4;
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     }
+    float sq = 0.f;
+    if (NORMS) {   // the squared norm, in row_sqnorms_kernel's lane layout and order (bit-identical to it)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            sq = fmaf(v[j].x, v[j].x, sq);
+            sq = fmaf(v[j].y, v[j].y, sq);
+            sq = fmaf(v[j].z, v[j].z, sq);
+            sq = fmaf(v[j].w, v[j].w, sq);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (lane == 0) *norm = sq;
+    } else if (is_w) {
+        sq = *norm;
+    }
+    if (is_w && lane == 0) se[row] = sqrtf(sq);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     int e = ((__float_as_int(m) >> 23) & 0xFF) - 127;   // floor(log2 m) for normal m
@@ -428,7 +451,7 @@ int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     return FilterWorkspace(N, K, D, 4 * MAX_SPLITS).total;
 }
 
-int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
+int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms, int64_t N,
                                   int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -469,15 +492,20 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, const float* x
         const dim3 pgrid(static_cast<unsigned>((rows + 3) / 4));
         const int nch = static_cast<int>((D + 255) / 256);
 #define T5VQ_PREP(NCH_)                                                                                          \
-    hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
-                       x_inv, w, static_cast<long long>(K), wb, w_inv, ee, static_cast<long long>(kpad), se,     \
-                       static_cast<int>(D), n_list)
-        if (nch <= 1) T5VQ_PREP(1);
-        else if (nch <= 2) T5VQ_PREP(2);
-        else if (nch <= 3) T5VQ_PREP(3);
-        else if (nch <= 4) T5VQ_PREP(4);
-        else if (nch <= 8) T5VQ_PREP(8);
-        else T5VQ_PREP(16);
+    if (compute_norms)                                                                                                 \
+        hipLaunchKernelGGL((filter_prep_kernel<NCH_, true>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),    \
+                           xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
+                           static_cast<int>(D), n_list);                                                                  \
+    else                                                                                                               \
+        hipLaunchKernelGGL((filter_prep_kernel<NCH_, false>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),   \
+                           xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
+                           static_cast<int>(D), n_list)
+        if (nch <= 1) { T5VQ_PREP(1); }
+        else if (nch <= 2) { T5VQ_PREP(2); }
+        else if (nch <= 3) { T5VQ_PREP(3); }
+        else if (nch <= 4) { T5VQ_PREP(4); }
+        else if (nch <= 8) { T5VQ_PREP(8); }
+        else { T5VQ_PREP(16); }
 #undef T5VQ_PREP
     }
     T5VQ_I_CHECK_HIP(hipGetLastError());

@@ -88,18 +88,27 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
     return keys
 
 
-def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False, exact_keys: bool = True):
+def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
-    (t5vq_dist_argmin_filtered_f32).  ``exact_keys=False``: only the index word is guaranteed (cheaper).
+    (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None: the row norms are computed by the call's own first pass
+    (no separate ``row_sqnorms``).  ``exact_keys=False``: only the index word is guaranteed (cheaper).
     Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``."""
     lib = _lib.load()
-    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
     k = w.shape[0]
-    if w.shape[1] != d or xx.shape[0] != n or ee.shape[0] != padded_codes(k):
-        raise RuntimeError("dist_argmin_filtered: inconsistent shapes")
+    if w.shape[1] != d:
+        raise RuntimeError("dist_argmin_filtered: x and w disagree on D")
     if d % 64:
         raise RuntimeError("the filtered search needs D % 64 == 0")
+    compute = xx is None or ee is None
+    if compute:
+        if xx is None:
+            xx = torch.empty(n, dtype=torch.float32, device=x.device)
+        ee = torch.empty(padded_codes(k), dtype=torch.float32, device=x.device)
+    _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
+    if xx.shape[0] != n or ee.shape[0] != padded_codes(k):
+        raise RuntimeError("dist_argmin_filtered: inconsistent shapes")
     if keys is None:
         keys = torch.empty(n, dtype=torch.int64, device=x.device)
     else:
@@ -108,9 +117,9 @@ def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow: bool = False, e
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, 1 if exact_keys else 0,
-                                                     _p(ws), nbytes, _p(keys), _p(ovf), _stream(x)),
-                   "dist_argmin_filtered")
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), 1 if compute else 0, n, k, d,
+                                                     1 if exact_keys else 0, _p(ws), nbytes, _p(keys), _p(ovf),
+                                                     _stream(x)), "dist_argmin_filtered")
     return (keys, ovf) if want_overflow else keys
 
 

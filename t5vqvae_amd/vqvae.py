@@ -125,14 +125,16 @@ class _QuantizerBase(nn.Module):
         if self.index_mode not in INDEX_MODES:
             raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
         if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
-            xx, ee = ops.row_sqnorms(x, w) if xx is None else (xx, ops.row_sqnorms(None, w)[1])
             if use_filter is None:
                 use_filter = self._use_filter(x, w, ranges)
             if use_filter:
-                keys = self._filtered_keys(x, w, xx, ee, exact_keys or code_offset != 0)
+                # the call's first pass writes the fp16 images AND the row norms (a given xx, e.g. from the encoder
+                # tail, is recomputed bit-identically rather than mixed with a separately computed ee)
+                keys = self._filtered_keys(x, w, exact_keys or code_offset != 0)
                 if code_offset:
                     keys = keys + code_offset          # index = low word; indices stay below 2^31: no carry
             else:
+                xx, ee = ops.row_sqnorms(x, w) if xx is None else (xx, ops.row_sqnorms(None, w)[1])
                 keys = ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
         else:
             order, rs = bucket_by_role(ranges)
@@ -167,8 +169,8 @@ class _QuantizerBase(nn.Module):
             return False
         return True
 
-    def _filtered_keys(self, x, w, xx, ee, exact_keys):
-        keys, ovf = ops.dist_argmin_filtered(x, w, xx, ee, want_overflow=True, exact_keys=exact_keys)
+    def _filtered_keys(self, x, w, exact_keys):
+        keys, ovf = ops.dist_argmin_filtered(x, w, want_overflow=True, exact_keys=exact_keys)
         if self.search == "auto" and not torch.cuda.is_current_stream_capturing():
             st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
             if st["pending"] is None:                  # asynchronous read-back of the unsettled-token count

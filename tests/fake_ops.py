@@ -61,7 +61,9 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
     return keys
 
 
-def dist_argmin_filtered(x, w, xx, ee, keys=None, want_overflow=False, exact_keys=True):
+def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True):
+    if xx is None or ee is None:
+        xx, ee = row_sqnorms(x, w)
     out = dist_argmin(x, w, xx, ee, keys=keys)
     return (out, torch.zeros(1, dtype=torch.int32)) if want_overflow else out
 

@@ -139,3 +139,15 @@ def test_filter_tracks_the_scan_through_codebook_collapse():
         assert torch.equal(idx.squeeze(1), scan & 0xFFFFFFFF)
     assert float(m._embedding.weight.abs().max()) > 1e4    # the codebook did collapse (dead codes blew up)
     assert max(unsettled) < n // 8
+
+
+def test_filter_computes_the_same_row_norms_itself():
+    from t5vqvae_amd import ops
+    n, k, d = 3000, 1000, 768
+    x = synth.normal((n, d), 91, 0, device="cuda")
+    w = synth.normal((k, d), 92, 0, device="cuda")
+    xx, ee = ops.row_sqnorms(x, w)
+    xx2 = torch.empty_like(xx)
+    k1 = ops.dist_argmin_filtered(x, w, xx, ee)
+    k2 = ops.dist_argmin_filtered(x, w, xx2, None)        # norms written by the call's own first pass
+    assert torch.equal(k1, k2) and torch.equal(xx, xx2)
