@@ -35,11 +35,12 @@ def states(workload, regime, dev):
     return w, ema_w, cs, x
 
 
-def gpu_time(workload, regime, dev, iters):
+def gpu_time(workload, regime, dev, iters, search="scan"):
     n, k, d, update, _ = bench.WORKLOADS[workload]
     w, ema_w, cs, x = states(workload, regime, dev)
     m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev).train(update)
     m.encodings = "indices"
+    m.search = search
     ts, used = [], 0
     with torch.no_grad():
         for i in range(iters + 2):
@@ -81,14 +82,16 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    lines = ["| config | regime | codes used | GPU ms (median / min) | M vectors/s | % fp32 MFMA roofline (2NKD) |"
-             " CPU ref vectors/s (slice) | speed-up |", "|---|---|---|---|---|---|---|---|"]
+    lines = ["| config | regime | codes used | scan: GPU ms (median / min) | M vectors/s | % fp32 MFMA roofline (2NKD) |"
+             " filtered search: GPU ms | M vectors/s | CPU ref vectors/s (slice) | scan speed-up |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
     for wl in ("c1", "c2", "c3", "c4"):
         n, k, d, update, desc = bench.WORKLOADS[wl]
         for regime in ("uniform", "cold", "collapsed"):
             med, mn, used = gpu_time(wl, regime, dev, args.iters)
             vps = n / med * 1e3
             frac = 2.0 * n * k * d / (med * 1e-3) / 1e12 / PEAK
+            fmed = gpu_time(wl, regime, dev, args.iters, "filter")[0] if d % 64 == 0 else float("nan")
             cpu = ""
             sp = ""
             if args.cpu and regime == "uniform":
@@ -96,7 +99,8 @@ def main():
                 cpu = f"{ns / ct:,.0f} ({ns} tokens, {torch.get_num_threads()} threads)"
                 sp = f"{vps / (ns / ct):,.0f}x"
             lines.append(f"| {wl.upper()} N={n} K={k} {'fwd+EMA' if update else 'fwd'} | {regime} | {used} | "
-                         f"{med:.4f} / {mn:.4f} | {vps / 1e6:.3f} | {100 * frac:.1f} | {cpu} | {sp} |")
+                         f"{med:.4f} / {mn:.4f} | {vps / 1e6:.3f} | {100 * frac:.1f} | {fmed:.4f} | "
+                         f"{n / fmed * 1e3 / 1e6:.3f} | {cpu} | {sp} |")
             print(lines[-1], flush=True)
     text = "\n".join(lines) + "\n"
     if args.out:
