@@ -1,3 +1,4 @@
+// build: hipcc -O2 -ffp-contract=off --offload-arch=gfx950 mfma_order.hip -o mfma_order ; result on MI355X: "fma-chain 1024" of 1024
 // Does v_mfma_f32_32x32x2_f32 accumulate like a k-ordered chain of fused multiply-adds?
 // One wave: C[32][32] = sum_k A[32][k] B[k][32], k < KD, by MFMA (2 k per instruction) and by three scalar candidates.
 #include <hip/hip_runtime.h>
