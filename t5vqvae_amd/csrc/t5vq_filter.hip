@@ -164,15 +164,26 @@ __device__ __forceinline__ void scan_insert(Scan& s, float l, int c) {  // keeps
 __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     const float* __restrict__ xb, const float* __restrict__ wb, const float* __restrict__ xx,
     const float* __restrict__ ee, const float* __restrict__ se, const float* __restrict__ x_inv,
-    const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, float c2,
+    const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, int plain_map,
+    float c2,
     float r, float* __restrict__ ubuf, float* __restrict__ lbuf, int* __restrict__ cbuf) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int wt = wave & 3, wc = wave >> 2;
-    const int grp = blockIdx.x / (8 * n_splits);
-    const int split = (blockIdx.x / 8) % n_splits;
-    const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
-    if (tok_base >= N) return;
+    // Large problems: the splits of one token tile get ids 8 apart (one XCD, shared X tile in its L2).  Small problems
+    // (plain_map: at most a few workgroups per CU in total): consecutive ids are different token tiles, so the
+    // workgroups spread evenly over the XCDs -- with 12 token tiles the XCD-affine map loads 4 XCDs twice as much.
+    int split, tok_base;
+    if (plain_map) {
+        const int tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+        split = blockIdx.x / tok_tiles;
+        tok_base = (blockIdx.x % tok_tiles) * TOK_TILE;
+    } else {
+        const int grp = blockIdx.x / (8 * n_splits);
+        split = (blockIdx.x / 8) % n_splits;
+        tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
+    }
+    if (tok_base >= N || split >= n_splits) return;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     const int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
@@ -432,7 +443,9 @@ struct FilterWorkspace {
 };
 constexpr int MAX_SPLITS = 8;
 
-// code splits (ids 8 apart = one XCD): fill 256 workgroup slots, at most MAX_SPLITS, at least 2 code tiles each
+// code splits: fill the 256 workgroup slots, at most MAX_SPLITS, at least 4 code tiles each (more, shorter splits
+// were measured slower at C1: 20 splits of 2 tiles 289 us vs 8 splits of 5 tiles 253 us -- per-workgroup set-up and
+// the scanner records grow with the split count)
 int64_t plan_filter_splits(int64_t N, int64_t K) {
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
@@ -448,7 +461,7 @@ extern "C" {
 
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     if (N < 0 || K < 0 || D < 0) return 0;
-    return FilterWorkspace(N, K, D, 4 * MAX_SPLITS).total;
+    return FilterWorkspace(N, K, D, 4 * plan_filter_splits(N, K)).total;
 }
 
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms, int64_t N,
@@ -525,10 +538,11 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
-    const dim3 grid(static_cast<unsigned>((tok_tiles + 7) / 8 * 8 * splits));
+    const int plain_map = tok_tiles * splits <= 1024 ? 1 : 0;
+    const dim3 grid(static_cast<unsigned>(plain_map ? tok_tiles * splits : (tok_tiles + 7) / 8 * 8 * splits));
     hipLaunchKernelGGL(filter_f16_kernel, grid, dim3(THREADS), LDS_BYTES, stream, reinterpret_cast<const float*>(xb),
                        reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv, static_cast<int>(N),
-                       static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2), static_cast<int>(splits), static_cast<int>(tiles_per_split), c2, r, ubuf,
+                       static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2), static_cast<int>(splits), static_cast<int>(tiles_per_split), plain_map, c2, r, ubuf,
                        lbuf, cbuf);
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
