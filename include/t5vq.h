@@ -155,7 +155,7 @@ int t5vq_cosine_backward_f32(const float* x, const float* q, const float* g_out,
 int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_stream_t stream);
 
 /* ---- The same search, filtered in fp16 and decided in fp32 (no reference counterpart: an implementation choice) --
- * keys[i] are bit-identical to t5vq_dist_argmin_f32(range = NULL, code_offset = 0, merge = 0): an fp16 MFMA pass
+ * keys[i] are bit-identical to t5vq_dist_argmin_f32(same range and code_offset, merge = 0): an fp16 MFMA pass
  * bounds every distance from both sides with a proven error bound, a second pass lists per token the codes whose
  * lower bound does not exceed the smallest upper bound (the fp32 argmin and everything tied with it are among them),
  * and the fp32 distance expression of t5vq_dist_argmin_f32 -- same summation order -- is evaluated for those codes
@@ -170,8 +170,9 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
  * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (fp16 images of x and w, bounds,
  * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan. */
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D);
-int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms, int64_t N,
-                                  int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
+int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
+                                  const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
+                                  int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream);
 
 /* ---- Evaluation-side searches (callers of the path in evaluate_vqvae.py) ----------------

@@ -161,12 +161,16 @@ __device__ __forceinline__ void scan_insert(Scan& s, float l, int c) {  // keeps
 // the fp32 scan kernel (token on the lane, codes in the accumulator registers); a 16-byte LDS fragment holds the
 // 8 fp16 a lane feeds one MFMA (lane (r, h): k = 8h + j of a 16-deep step).  D2 = D / 2 = row length in 4-byte units.
 // Output per scanner and token: umin and the KEEP kept (lower bound, code) pairs, token-minor for coalescing.
+// RANGED (disentangled codebook): token i may only take codes [start_i, end_i) (global ids; this codebook slice
+// starts at code_offset); codes outside get U = +inf and L = NaN, and code tiles outside the workgroup's ranges are
+// skipped (the module buckets tokens by role, so a workgroup sees one or two ranges).
+template <bool RANGED>
 __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     const float* __restrict__ xb, const float* __restrict__ wb, const float* __restrict__ xx,
     const float* __restrict__ ee, const float* __restrict__ se, const float* __restrict__ x_inv,
     const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, int plain_map,
-    float c2,
-    float r, float* __restrict__ ubuf, float* __restrict__ lbuf, int* __restrict__ cbuf) {
+    float c2, float r, const long long* __restrict__ range, long long code_offset, float* __restrict__ ubuf,
+    float* __restrict__ lbuf, int* __restrict__ cbuf) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int wt = wave & 3, wc = wave >> 2;
@@ -185,15 +189,14 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     }
     if (tok_base >= N || split >= n_splits) return;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
-    const int tile_begin = split * tiles_per_split;
+    int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
-    const int n_tiles = tile_end - tile_begin;
     const int n_chunks = D2 / BKC;  // D % 64 == 0 is required by the launcher
-    const int total = n_tiles * n_chunks;
 
     Scan sc[TB];
     int tok[TB];
+    int ls[TB], le[TB];   // RANGED: admissible local codes [ls, le)
     float xv[TB], csx[TB], m2[TB];
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
@@ -203,7 +206,46 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
         xv[b] = xx[tc];
         csx[b] = c2 * sqrtf(xv[b]);
         m2[b] = -2.0f * x_inv[tc];   // -2 and the token row's inverse scale: exact (power of two)
+        ls[b] = 0;
+        le[b] = K;
+        if (RANGED) {
+            long long a = range[2 * static_cast<size_t>(tc)] - code_offset;
+            long long e = range[2 * static_cast<size_t>(tc) + 1] - code_offset;
+            a = a < 0 ? 0 : (a > K ? K : a);
+            e = e < 0 ? 0 : (e > K ? K : e);
+            ls[b] = static_cast<int>(a);
+            le[b] = static_cast<int>(e);
+        }
     }
+    if (RANGED) {   // the workgroup's [lowest start, highest end): code tiles outside it are not visited
+        int lo_c = 0x7FFFFFFF, hi_c = 0;
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+            if (tok[b] < N && le[b] > ls[b]) {
+                lo_c = min(lo_c, ls[b]);
+                hi_c = max(hi_c, le[b]);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo_c = min(lo_c, __shfl_xor(lo_c, o));
+            hi_c = max(hi_c, __shfl_xor(hi_c, o));
+        }
+        int* red = reinterpret_cast<int*>(lds);
+        if (lane == 0) {
+            red[2 * wave] = lo_c;
+            red[2 * wave + 1] = hi_c;
+        }
+        __syncthreads();
+        for (int i = 0; i < THREADS / 64; ++i) {
+            lo_c = min(lo_c, red[2 * i]);
+            hi_c = max(hi_c, red[2 * i + 1]);
+        }
+        __syncthreads();   // the staging writes below reuse this LDS
+        tile_begin = max(tile_begin, lo_c / CODE_TILE);
+        tile_end = min(tile_end, (hi_c + CODE_TILE - 1) / CODE_TILE);
+    }
+    const int n_tiles = tile_end - tile_begin;
+    const int total = n_tiles * n_chunks;
 
     if (n_tiles > 0) {
         const int s_row = tid / F4_PER_ROW, s_col = (tid % F4_PER_ROW) * 4;
@@ -299,8 +341,14 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                             const float s = xv[b] + e4[c];
                             const float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);   // -2 dot~, rescaled exactly
                             const float delta = fmaf(csx[b], s4[c], r * s);
-                            sc[b].umin = fminf(sc[b].umin, d + delta);   // padded codes: +inf
+                            float up = d + delta;                        // padded codes: +inf
                             lo[c] = d - delta;                           // padded codes: inf - inf = NaN
+                            if (RANGED) {
+                                const bool ok = cb + c >= ls[b] && cb + c < le[b];
+                                up = ok ? up : __int_as_float(0x7F800000);
+                                lo[c] = ok ? lo[c] : __int_as_float(0x7FC00000);   // NaN: never a candidate
+                            }
+                            sc[b].umin = fminf(sc[b].umin, up);
                             lmin = fminf(lmin, lo[c]);                   // fminf drops the NaN
                         }
                         // only a lower bound below both the smallest upper bound so far and the worst kept one matters
@@ -332,9 +380,10 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 // KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int n_scanners,
-                                                      int exact_keys, int* __restrict__ cnt, int* __restrict__ cand,
-                                                      long long* __restrict__ keys, int* __restrict__ tok_list,
-                                                      int* __restrict__ n_list) {
+                                                      int exact_keys, const long long* __restrict__ range,
+                                                      long long code_offset, int* __restrict__ cnt,
+                                                      int* __restrict__ cand, long long* __restrict__ keys,
+                                                      int* __restrict__ tok_list, int* __restrict__ n_list) {
     const int tok = blockIdx.x * 256 + threadIdx.x;
     if (tok >= N) return;
     float T = __int_as_float(0x7F800000);
@@ -356,12 +405,13 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         }
         overflow |= q == KEEP;
     }
-    if (overflow || n > CAND_MAX || n == 0) {   // n == 0 cannot happen for finite inputs; NaN rows take the scan too
-        keys[tok] = KEY_NONE;                   // the listed scan merges into it with atomicMin
+    if (overflow || n > CAND_MAX || n == 0) {   // n == 0: a range that misses this codebook slice (key stays 'none'),
+        keys[tok] = KEY_NONE;                   // or a NaN row; the listed scan merges into it with atomicMin
         tok_list[atomicAdd(n_list, 1)] = tok;
         cnt[tok] = 0;
     } else if (n == 1 && !exact_keys) {         // the index is decided; T_i (an upper bound of its distance) fills
-        keys[tok] = pack_key(T, first);         // the key's distance word
+        const long long gi = code_offset + first - (range ? range[2 * static_cast<size_t>(tok)] : 0);
+        keys[tok] = pack_key(T, static_cast<int>(gi));   // the key's distance word (index: slice-relative if ranged)
         cnt[tok] = 0;
     } else {
         cnt[tok] = n;
@@ -399,7 +449,8 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ xr, co
 // ---- refine: one lane per (token, candidate slot); a token's CAND_MAX lanes sit side by side ------------------
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ xx, const float* __restrict__ ee,
-                                                     int N, int K, int D, const int* __restrict__ cnt,
+                                                     int N, int K, int D, const long long* __restrict__ range,
+                                                     long long code_offset, const int* __restrict__ cnt,
                                                      const int* __restrict__ cand, long long* __restrict__ keys) {
     const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
     const int tok = static_cast<int>(gid / CAND_MAX);
@@ -410,8 +461,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x
         n = cnt[tok];
         if (slot < n) {
             const int code = cand[static_cast<size_t>(tok) * CAND_MAX + slot];
+            const long long gi = code_offset + code - (range ? range[2 * static_cast<size_t>(tok)] : 0);
             key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D, w + static_cast<size_t>(code) * D, D,
-                                          xx[tok], ee[code]), code);
+                                          xx[tok], ee[code]), static_cast<int>(gi));
         }
     }
 #pragma unroll
@@ -464,13 +516,15 @@ int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     return FilterWorkspace(N, K, D, 4 * plan_filter_splits(N, K)).total;
 }
 
-int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms, int64_t N,
-                                  int64_t K, int64_t D, int exact_keys, void* workspace, int64_t workspace_bytes,
+int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
+                                  const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
+                                  int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
     T5VQ_I_REQUIRE(D >= 64 && D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, 64 <= D <= 4096");
+    T5VQ_I_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
     T5VQ_I_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0 &&
                        (reinterpret_cast<uintptr_t>(ee) & 15u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                    "x, w, ee must be 16-byte aligned and the workspace 256-byte aligned");
@@ -481,7 +535,9 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     int dev = 0;
     T5VQ_I_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel),
+        T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done[dev] = true;
     }
@@ -540,21 +596,29 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int plain_map = tok_tiles * splits <= 1024 ? 1 : 0;
     const dim3 grid(static_cast<unsigned>(plain_map ? tok_tiles * splits : (tok_tiles + 7) / 8 * 8 * splits));
-    hipLaunchKernelGGL(filter_f16_kernel, grid, dim3(THREADS), LDS_BYTES, stream, reinterpret_cast<const float*>(xb),
-                       reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv, static_cast<int>(N),
-                       static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2), static_cast<int>(splits), static_cast<int>(tiles_per_split), plain_map, c2, r, ubuf,
-                       lbuf, cbuf);
+    const long long* rg = reinterpret_cast<const long long*>(range);
+#define T5VQ_FILTER_ARGS                                                                                              \
+    reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv,                 \
+        static_cast<int>(N), static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2),                    \
+        static_cast<int>(splits), static_cast<int>(tiles_per_split), plain_map, c2, r, rg,                           \
+        static_cast<long long>(code_offset), ubuf, lbuf, cbuf
+    if (range)
+        hipLaunchKernelGGL((filter_f16_kernel<true>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
+    else
+        hipLaunchKernelGGL((filter_f16_kernel<false>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
+#undef T5VQ_FILTER_ARGS
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
-                       cbuf, static_cast<int>(N), static_cast<int>(scanners), exact_keys, cnt, cand,
-                       reinterpret_cast<long long*>(keys), tok_list, n_list);
+                       cbuf, static_cast<int>(N), static_cast<int>(scanners), exact_keys, rg,
+                       static_cast<long long>(code_offset), cnt, cand, reinterpret_cast<long long*>(keys), tok_list,
+                       n_list);
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
-                       xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), cnt, cand,
-                       reinterpret_cast<long long*>(keys));
+                       xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), rg,
+                       static_cast<long long>(code_offset), cnt, cand, reinterpret_cast<long long*>(keys));
     T5VQ_I_CHECK_HIP(hipGetLastError());
     // tokens the filter could not settle: the fp32 scan kernel itself, on those tokens only
-    const int rc = t5vq_internal_scan_listed(x, w, xx, ee, N, K, D, tok_list, n_list, keys, stream);
+    const int rc = t5vq_internal_scan_listed(x, w, xx, ee, range, N, K, D, code_offset, tok_list, n_list, keys, stream);
     if (rc != T5VQ_OK) return rc;
     if (n_overflow) T5VQ_I_CHECK_HIP(hipMemcpyAsync(n_overflow, n_list, 4, hipMemcpyDeviceToDevice, stream));
     return T5VQ_OK;

@@ -7,9 +7,9 @@
 #include "t5vq.h"
 
 int t5vq_internal_fail(int code, const char* fmt, const char* a, const char* b);
-extern "C" int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee, int64_t N,
-                                         int64_t K, int64_t D, const int* tok_list, const int* n_listed, int64_t* keys,
-                                         hipStream_t stream);
+extern "C" int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee,
+                                         const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
+                                         const int* tok_list, const int* n_listed, int64_t* keys, hipStream_t stream);
 
 #define T5VQ_I_CHECK_HIP(expr)                                                                         \
     do {                                                                                               \

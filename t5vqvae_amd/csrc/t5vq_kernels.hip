@@ -1383,6 +1383,8 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, true, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         if (V2) {
             T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -1433,7 +1435,10 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     } else if (v2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
-    } else if (opts.tok_list) {  // listed tokens only, one code tile per workgroup, merged with atomicMin
+    } else if (opts.tok_list && range) {  // listed tokens only, one code tile per workgroup, merged with atomicMin
+        hipLaunchKernelGGL((dist_mfma_kernel<C, true, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
+                           T5VQ_DIST_ARGS, 1, kp, dist, opts.tok_list, opts.n_listed);
+    } else if (opts.tok_list) {
         hipLaunchKernelGGL((dist_mfma_kernel<C, false, false, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, 1, kp, dist, opts.tok_list, opts.n_listed);
     } else if (opts.bounded) {  // top-k pass: `range` carries one excluded key per token
@@ -1805,12 +1810,13 @@ int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const fl
 }
 
 // Internal (t5vq_internal.h): fp32 scan of the tokens in tok_list[0 .. *n_listed) only; their keys must hold KEY_NONE.
-int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
-                              int64_t D, const int* tok_list, const int* n_listed, int64_t* keys, hipStream_t stream) {
+int t5vq_internal_scan_listed(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
+                              int64_t N, int64_t K, int64_t D, int64_t code_offset, const int* tok_list,
+                              const int* n_listed, int64_t* keys, hipStream_t stream) {
     DistOpts opts;
     opts.tok_list = tok_list;
     opts.n_listed = n_listed;
-    return launch_dist_cfg<CfgDefault, false>(x, w, xx, ee, nullptr, N, K, D, 0, 1, keys, nullptr, stream, opts);
+    return launch_dist_cfg<CfgDefault, false>(x, w, xx, ee, range, N, K, D, code_offset, 1, keys, nullptr, stream, opts);
 }
 
 int t5vq_dist_topk_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,

@@ -88,7 +88,8 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
     return keys
 
 
-def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True):
+def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True,
+                         ranges=None, code_offset: int = 0):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
     (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None: the row norms are computed by the call's own first pass
     (no separate ``row_sqnorms``).  ``exact_keys=False``: only the index word is guaranteed (cheaper).
@@ -101,6 +102,10 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
         raise RuntimeError("dist_argmin_filtered: x and w disagree on D")
     if d % 64:
         raise RuntimeError("the filtered search needs D % 64 == 0")
+    if ranges is not None:
+        _need(ranges, "ranges", torch.int64, 2)
+        if tuple(ranges.shape) != (n, 2):
+            raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
     compute = xx is None or ee is None
     if compute:
         if xx is None:
@@ -117,9 +122,9 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), 1 if compute else 0, n, k, d,
-                                                     1 if exact_keys else 0, _p(ws), nbytes, _p(keys), _p(ovf),
-                                                     _stream(x)), "dist_argmin_filtered")
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), 1 if compute else 0, _p(ranges),
+                                                     n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
+                                                     _p(keys), _p(ovf), _stream(x)), "dist_argmin_filtered")
     return (keys, ovf) if want_overflow else keys
 
 

@@ -107,7 +107,7 @@ class _QuantizerBase(nn.Module):
     # How the nearest code is found.  "scan": fused fp32 MFMA distance + argmin over all codes.  "filter": an fp16
     # MFMA pass with a proven error bound leaves the few codes that can be the fp32 argmin and the scan's fp32
     # arithmetic decides among them -- the SAME indices, bit for bit, several times faster on large problems.
-    # "auto": filter when it applies (no role ranges, D % 64 == 0) and pays (N*K >= filter_min_work), with a
+    # "auto": filter when it applies (D % 64 == 0) and pays (N*K >= filter_min_work), with a
     # back-off to the scan while the filter leaves too many tokens unsettled (degenerate codebooks: all rows equal).
     search = "auto"
     filter_min_work = 1 << 24    # N*K below which the scan is faster (C2: 2e6 -> scan; C1: 2.9e7 -> filter)
@@ -124,34 +124,32 @@ class _QuantizerBase(nn.Module):
         costs 2 D sum_r N_r K_r flops instead of 2 D N K.  Keys are scattered back to token order."""
         if self.index_mode not in INDEX_MODES:
             raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
+        if use_filter is None:
+            use_filter = self._use_filter(x, w, ranges)
         if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
-            if use_filter is None:
-                use_filter = self._use_filter(x, w, ranges)
             if use_filter:
                 # the call's first pass writes the fp16 images AND the row norms (a given xx, e.g. from the encoder
                 # tail, is recomputed bit-identically rather than mixed with a separately computed ee)
-                keys = self._filtered_keys(x, w, exact_keys or code_offset != 0)
-                if code_offset:
-                    keys = keys + code_offset          # index = low word; indices stay below 2^31: no carry
-            else:
-                xx, ee = ops.row_sqnorms(x, w) if xx is None else (xx, ops.row_sqnorms(None, w)[1])
-                keys = ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
+                return self._filtered_keys(x, w, exact_keys or code_offset != 0, ranges, code_offset)
+            xx, ee = ops.row_sqnorms(x, w) if xx is None else (xx, ops.row_sqnorms(None, w)[1])
+            return ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
+        order, rs = bucket_by_role(ranges)
+        xs = x.index_select(0, order)
+        if use_filter:
+            ks = self._filtered_keys(xs, w, exact_keys or code_offset != 0, rs, code_offset)
         else:
-            order, rs = bucket_by_role(ranges)
-            xs = x.index_select(0, order)
             xx, ee = ops.row_sqnorms(xs, w)
             ks = ops.dist_argmin(xs, w, xx, ee, rs, code_offset=code_offset)
-            keys = torch.empty_like(ks).index_copy_(0, order, ks)
-        return keys
+        return torch.empty_like(ks).index_copy_(0, order, ks)
 
     def _use_filter(self, x, w, ranges) -> bool:
         if self.search not in ("auto", "scan", "filter"):
             raise ValueError(f"search must be 'auto', 'scan' or 'filter', got {self.search!r}")
         n, d = x.shape
-        eligible = ranges is None and d % 64 == 0 and d <= 4096
+        eligible = d % 64 == 0 and d <= 4096
         if self.search == "scan" or not eligible:
             if self.search == "filter":
-                raise RuntimeError("search='filter' needs D % 64 == 0, D <= 4096 and no role ranges")
+                raise RuntimeError("search='filter' needs D % 64 == 0 and D <= 4096")
             return False
         if self.search == "filter":
             return True
@@ -169,8 +167,9 @@ class _QuantizerBase(nn.Module):
             return False
         return True
 
-    def _filtered_keys(self, x, w, exact_keys):
-        keys, ovf = ops.dist_argmin_filtered(x, w, want_overflow=True, exact_keys=exact_keys)
+    def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0):
+        keys, ovf = ops.dist_argmin_filtered(x, w, want_overflow=True, exact_keys=exact_keys, ranges=ranges,
+                                             code_offset=code_offset)
         if self.search == "auto" and not torch.cuda.is_current_stream_capturing():
             st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
             if st["pending"] is None:                  # asynchronous read-back of the unsettled-token count

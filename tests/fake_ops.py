@@ -61,10 +61,11 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
     return keys
 
 
-def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True):
+def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True, ranges=None,
+                         code_offset=0):
     if xx is None or ee is None:
         xx, ee = row_sqnorms(x, w)
-    out = dist_argmin(x, w, xx, ee, keys=keys)
+    out = dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, keys=keys)
     return (out, torch.zeros(1, dtype=torch.int32)) if want_overflow else out
 
 

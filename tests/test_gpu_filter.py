@@ -151,3 +151,51 @@ def test_filter_computes_the_same_row_norms_itself():
     k1 = ops.dist_argmin_filtered(x, w, xx, ee)
     k2 = ops.dist_argmin_filtered(x, w, xx2, None)        # norms written by the call's own first pass
     assert torch.equal(k1, k2) and torch.equal(xx, xx2)
+
+
+@pytest.mark.parametrize("n,k,d,offset", [(4096, 2048, 768, 0), (1000, 700, 128, 0), (3000, 1024, 768, 1024),
+                                          (65536, 8192, 768, 0)])
+def test_filtered_keys_identical_to_scan_with_role_ranges(n, k, d, offset):
+    """Disentangled form: per-token [start, end) ranges in global code ids, a codebook slice that starts at
+    `offset`; ranges that straddle the slice, miss it entirely, or are empty.  Keys (slice-relative indices, 'none'
+    for tokens without an admissible code) must equal the scan's."""
+    from t5vqvae_amd import ops
+    w = synth.normal((k, d), 93, 0, device="cuda")
+    x = synth.normal((n, d), 94, 0, device="cuda")
+    hi = offset + k
+    roles = [(offset, offset + k // 5), (offset + k // 5, offset + k // 5 + 1), (offset + k // 5 + 1, offset + k // 2),
+             (offset + k // 2, hi), (max(0, offset - 300), offset + 40), (hi - 17, hi + 500), (hi + 10, hi + 90),
+             (offset + 7, offset + 7)]
+    rg = synth.role_ranges(n, roles, 95, 0, device="cuda")
+    order = torch.argsort(rg[:, 0] * (1 << 32) + rg[:, 1], stable=True)
+    for ranges, xs in ((rg, x), (rg.index_select(0, order), x.index_select(0, order))):   # token order, role-bucketed
+        xx, ee = ops.row_sqnorms(xs, w)
+        scan = ops.dist_argmin(xs, w, xx, ee, ranges, code_offset=offset)
+        filt, ovf = ops.dist_argmin_filtered(xs, w, xx, ee, want_overflow=True, ranges=ranges, code_offset=offset)
+        assert torch.equal(scan, filt), (int((scan != filt).sum()), int(ovf))
+        fidx = ops.dist_argmin_filtered(xs, w, ranges=ranges, code_offset=offset, exact_keys=False)
+        none = scan == 0x7FFFFFFFFFFFFFFF
+        assert torch.equal(none, fidx == 0x7FFFFFFFFFFFFFFF)
+        assert torch.equal((scan & 0xFFFFFFFF)[~none], (fidx & 0xFFFFFFFF)[~none])
+    assert int(none.sum()) > 0                               # the empty / missing ranges were exercised
+
+
+def test_disentangled_module_filter_equals_scan():
+    from t5vqvae_amd import VectorQuantizerEMA
+    n, k, d = 8192, 4096, 768
+    w, ew = synth.normal((k, d), 96, 0), synth.normal((k, d), 96, 1)
+    x = synth.normal((8, n // 8, d), 97, 0).cuda()
+    srl = synth.role_ranges(n, [(0, 1000), (1000, 1500), (1500, 4096)], 98, 0, device="cuda").view(8, n // 8, 2)
+    outs = {}
+    for search in ("scan", "filter", "auto"):
+        for mode in ("reference", "absolute"):
+            m = VectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=True).cuda()
+            with torch.no_grad():
+                m._embedding.weight.copy_(w), m._ema_w.copy_(ew)
+            m.encodings, m.search, m.index_mode = "indices", search, mode
+            outs[(search, mode)] = m(x, srl)
+    for mode in ("reference", "absolute"):
+        a = outs[("scan", mode)]
+        for search in ("filter", "auto"):
+            b = outs[(search, mode)]
+            assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
