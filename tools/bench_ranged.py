@@ -1,4 +1,6 @@
-"""Grouped (disentangled) distance kernel: time with and without role bucketing.  python3 tools/bench_ranged.py"""
+"""Grouped (disentangled) nearest-code search: scan and filtered search, with and without role bucketing.
+
+    python3 tools/bench_ranged.py"""
 import os
 import sys
 
@@ -32,10 +34,16 @@ for n, k, roles, name in [
     srl = synth.role_ranges(n, roles, 5, 1, device=dev).view(1, n, 2)
     flops = 2.0 * d * sum(float((srl.view(-1, 2)[:, 0] == a).sum()) * (b - a) for a, b in roles)
     res = {}
-    for bucket in (False, True):
-        m.bucket_roles = bucket
-        res[bucket] = timed(lambda: m.get_indices(x, srl))
+    ref = None
+    for search in ("scan", "filter"):
+        m.search = search
+        for bucket in (False, True):
+            m.bucket_roles = bucket
+            idx = m.get_indices(x, srl)
+            ref = idx if ref is None else ref
+            assert torch.equal(idx, ref)
+            res[(search, bucket)] = timed(lambda: m.get_indices(x, srl))
     full = 2.0 * n * k * d
-    print(f"N={n} K={k} {name}: unbucketed {res[False]:.3f} ms, bucketed {res[True]:.3f} ms "
-          f"(grouped flops {flops/1e9:.0f} G of dense {full/1e9:.0f} G -> {flops/res[True]/1e9:.1f} TF/s grouped-algorithmic)",
-          flush=True)
+    print(f"N={n} K={k} {name}: scan unbucketed {res[('scan', False)]:.3f} ms, bucketed {res[('scan', True)]:.3f} ms | "
+          f"filtered unbucketed {res[('filter', False)]:.3f} ms, bucketed {res[('filter', True)]:.3f} ms "
+          f"(grouped flops {flops/1e9:.0f} G of dense {full/1e9:.0f} G; identical indices)", flush=True)
