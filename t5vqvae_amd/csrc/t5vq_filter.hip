@@ -379,13 +379,22 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 // ---- collect: T_i = min over scanners of umin; candidates = kept pairs with lower bound <= T_i.  A scanner whose
 // KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
-                                                      const int* __restrict__ cbuf, int N, int n_scanners,
+                                                      const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
                                                       long long code_offset, int* __restrict__ cnt,
                                                       int* __restrict__ cand, long long* __restrict__ keys,
                                                       int* __restrict__ tok_list, int* __restrict__ n_list) {
     const int tok = blockIdx.x * 256 + threadIdx.x;
     if (tok >= N) return;
+    if (range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
+        const long long a = range[2 * static_cast<size_t>(tok)] - code_offset;
+        const long long e = range[2 * static_cast<size_t>(tok) + 1] - code_offset;
+        if ((e < K ? e : K) <= (a > 0 ? a : 0)) {
+            keys[tok] = KEY_NONE;
+            cnt[tok] = 0;
+            return;
+        }
+    }
     float T = __int_as_float(0x7F800000);
     for (int s = 0; s < n_scanners; ++s) T = fminf(T, ubuf[static_cast<size_t>(s) * N + tok]);
     int n = 0, first = -1;
@@ -405,8 +414,8 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         }
         overflow |= q == KEEP;
     }
-    if (overflow || n > CAND_MAX || n == 0) {   // n == 0: a range that misses this codebook slice (key stays 'none'),
-        keys[tok] = KEY_NONE;                   // or a NaN row; the listed scan merges into it with atomicMin
+    if (overflow || n > CAND_MAX || n == 0) {   // n == 0: NaN / inf rows -- whatever the scan does with them
+        keys[tok] = KEY_NONE;                   // the listed scan merges into it with atomicMin
         tok_list[atomicAdd(n_list, 1)] = tok;
         cnt[tok] = 0;
     } else if (n == 1 && !exact_keys) {         // the index is decided; T_i (an upper bound of its distance) fills
@@ -609,7 +618,7 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
 #undef T5VQ_FILTER_ARGS
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
-                       cbuf, static_cast<int>(N), static_cast<int>(scanners), exact_keys, rg,
+                       cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners), exact_keys, rg,
                        static_cast<long long>(code_offset), cnt, cand, reinterpret_cast<long long*>(keys), tok_list,
                        n_list);
     T5VQ_I_CHECK_HIP(hipGetLastError());

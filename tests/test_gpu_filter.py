@@ -173,6 +173,7 @@ def test_filtered_keys_identical_to_scan_with_role_ranges(n, k, d, offset):
         scan = ops.dist_argmin(xs, w, xx, ee, ranges, code_offset=offset)
         filt, ovf = ops.dist_argmin_filtered(xs, w, xx, ee, want_overflow=True, ranges=ranges, code_offset=offset)
         assert torch.equal(scan, filt), (int((scan != filt).sum()), int(ovf))
+        assert int(ovf) < n // 20                            # tokens whose range misses the slice are not rescanned
         fidx = ops.dist_argmin_filtered(xs, w, ranges=ranges, code_offset=offset, exact_keys=False)
         none = scan == 0x7FFFFFFFFFFFFFFF
         assert torch.equal(none, fidx == 0x7FFFFFFFFFFFFFFF)
