@@ -1,6 +1,6 @@
 """Small driver for profiler passes: a few launches of the hot kernels at a BASELINE shape.
 
-    python3 tools/run_kernels.py [c3|c1|c2|c4] [reps] [dist|step]
+    python3 tools/run_kernels.py [c3|c1|c2|c4] [reps] [dist|step] [scan|filter|auto]
 """
 import os
 import sys
@@ -14,6 +14,7 @@ from t5vqvae_amd import VectorQuantizerEMA, ops  # noqa: E402
 workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 what = sys.argv[3] if len(sys.argv) > 3 else "step"
+search = sys.argv[4] if len(sys.argv) > 4 else "scan"   # the benchmark's headline mode
 from t5vqvae_amd import _lib  # noqa: E402
 _lib.load().t5vq_set_tuning(int(os.environ.get("T5VQ_TUNE", "0")))
 dev = torch.device("cuda", 0)
@@ -32,6 +33,7 @@ else:
         mod._ema_w.copy_(ema_w)
         mod._ema_cluster_size.copy_(cs)
         mod.encodings = "indices"
+        mod.search = search
         mod.train(update)
         for _ in range(reps):
             mod(x)
