@@ -589,13 +589,14 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     T5VQ_I_CHECK_HIP(hipGetLastError());
 
     // error coefficient of the fp16 dot product against the fp32 chain, relative to |x| |e|:
-    // two operand roundings (u = 2^-11 each; elements below 2^-28 of their row maximum fall into fp16's denormals,
-    // absolute error 2^-39 of the maximum: the sqrt(D) 2^-37 term), the matrix pipe's fp32 accumulation of the exact
+    // two operand roundings (u = 2^-11 each; elements below 2^-28 of their row maximum fall into fp16's denormals:
+    // absolute error 2^-39 of the maximum when rounded, 2^-28 if the pipe flushed them to zero -- the sqrt(D) 2^-26
+    // term covers both operands either way), the matrix pipe's fp32 accumulation of the exact
     // products (<= D 2^-22), the chain's own rounding (<= 1.01 D 2^-24); doubled because the distance carries 2 dot;
     // 2 % margin for the fp32 evaluation of the bound itself.  r covers the roundings of the distance expression and
     // of the bound's sums.
     const double u = 1.0 / 2048.0;
-    const double c_dot = (2 * u + u * u) + sqrt(static_cast<double>(D)) * (1.0 / 137438953472.0) +
+    const double c_dot = (2 * u + u * u) + sqrt(static_cast<double>(D)) * (1.0 / 67108864.0) +
                          D * (1.0 / 4194304.0) + 1.01 * D * (1.0 / 16777216.0);
     const float c2 = static_cast<float>(2.0 * c_dot * 1.02);
     const float r = 1.0f / 1048576.0f;  // 2^-20

@@ -17,6 +17,7 @@ Differences that are visible and deliberate:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -26,6 +27,16 @@ from . import ops
 from .roles import INDEX_MODES, bucket_by_role
 
 _KEY_NONE = 0x7FFFFFFFFFFFFFFF
+# per-module state of the search="auto" back-off (events and pinned buffers: kept out of the module's __dict__ so
+# that copy.deepcopy / pickling of the module are unaffected)
+_FILTER_STATE = weakref.WeakKeyDictionary()
+
+
+def _filter_state(module):
+    st = _FILTER_STATE.get(module)
+    if st is None:
+        st = _FILTER_STATE[module] = {"skip": 0, "pending": None}
+    return st
 
 
 class _Plan:
@@ -155,7 +166,7 @@ class _QuantizerBase(nn.Module):
             return True
         if n * w.shape[0] < self.filter_min_work:
             return False
-        st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
+        st = _filter_state(self)
         if st["pending"] is not None and not torch.cuda.is_current_stream_capturing():
             event, host, n_prev = st["pending"]
             if event.query():                          # the previous call's count has landed: no host wait
@@ -171,7 +182,7 @@ class _QuantizerBase(nn.Module):
         keys, ovf = ops.dist_argmin_filtered(x, w, want_overflow=True, exact_keys=exact_keys, ranges=ranges,
                                              code_offset=code_offset)
         if self.search == "auto" and not torch.cuda.is_current_stream_capturing():
-            st = self.__dict__.setdefault("_filter_state", {"skip": 0, "pending": None})
+            st = _filter_state(self)
             if st["pending"] is None:                  # asynchronous read-back of the unsettled-token count
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(ovf, non_blocking=True)

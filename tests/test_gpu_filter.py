@@ -97,7 +97,8 @@ def test_module_filter_and_scan_give_the_same_step():
 
 
 def test_auto_backs_off_on_a_degenerate_codebook():
-    from t5vqvae_amd import VectorQuantizerEMA
+    import copy
+    from t5vqvae_amd import VectorQuantizerEMA, vqvae as hv
     n, k, d = 8192, 4096, 768
     m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda().eval()
     with torch.no_grad():
@@ -110,8 +111,10 @@ def test_auto_backs_off_on_a_degenerate_codebook():
         idx = m(x)[3]
         torch.cuda.synchronize()
         assert torch.equal(idx.cpu(), ref)
-        used.append(m.__dict__["_filter_state"]["skip"])
+        used.append(hv._filter_state(m)["skip"])
     assert used[0] == 0 and max(used) > 0                  # the first call filters, the count comes back, then scan
+    m2 = copy.deepcopy(m)                                   # the back-off state does not travel with the module
+    assert hv._filter_state(m2)["skip"] == 0 and torch.equal(m2(x)[3].cpu(), ref)
 
 
 def test_filter_tracks_the_scan_through_codebook_collapse():
