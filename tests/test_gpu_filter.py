@@ -203,3 +203,24 @@ def test_disentangled_module_filter_equals_scan():
         for search in ("filter", "auto"):
             b = outs[(search, mode)]
             assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_filter_survives_worst_case_aligned_rounding():
+    """Operands built so that every fp16 rounding error has the same sign and the maximal size (elements just below
+    the midpoint between two fp16 values, all products of one sign): the fp16 distances then RANK THE WRONG CODE FIRST
+    by ~80 % of the error bound.  The bound must keep the right code among the candidates: keys equal the scan's."""
+    from t5vqvae_amd import ops
+    n, d = 512, 768
+    a = 1.0 + 0.99 * 2.0 ** -11                            # rounds to 1.0 in fp16: relative error ~2^-11
+    signs = (synth.uniform_int(n * d, 2, 101, 0).view(n, d).float() * 2 - 1).cuda()
+    x = (signs * a).contiguous()
+    w = torch.cat([x, signs], 0).contiguous()              # code i = x_i exactly; code n + i = its fp16 image
+    scan, filt, ovf = both(x, w)
+    assert torch.equal(scan, filt), int((scan != filt).sum())
+    idx = (scan & 0xFFFFFFFF).cpu()
+    tok = torch.arange(n)
+    assert bool(((idx == tok) | (idx == tok + n)).all())   # one of the two near-twins, as fp32 arithmetic decides
+    assert int((idx == tok).sum()) > n // 2                # mostly the exact match, which fp16 alone ranks second
+    for scale_x, scale_w in ((1e-3, 1e3), (37.0, 1.0 / 37.0)):   # row scalings must not matter
+        scan, filt, _ = both((x * scale_x).contiguous(), (w * scale_w).contiguous())
+        assert torch.equal(scan, filt)
