@@ -101,3 +101,16 @@ def test_mid_encoder_call_site_returns_pair():
     assert hidden_q.shape == hidden.shape and recon_loss.dim() == 0
     (hidden_q.pow(2).mean() + recon_loss).backward()
     assert hidden.grad is not None and torch.isfinite(hidden.grad).all()
+
+
+def test_c_abi_demo_program_runs_without_python_bindings():
+    """examples/c_abi_demo.cpp: a C++ program that drives one training step through include/t5vq.h alone (hipMalloc'ed
+    buffers, its own stream) and checks the indices -- and the filtered search's -- on the host."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    assert os.path.exists(exe), "build it with make -C t5vqvae_amd/csrc demo (done by __graft_entry__.build())"
+    out = subprocess.run([exe, "2048", "700"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "index mismatches 0" in out.stdout and "differs on 0 tokens" in out.stdout
