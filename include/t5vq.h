@@ -129,6 +129,24 @@ int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* 
 int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
                        int64_t D, float decay, float one_minus_decay, t5vq_stream_t stream);
 
+/* ---- Order-independent EMA statistics (opt-in; no reference counterpart: the reference's matmul(encodings.t(),
+ * flat_input), vqvae/vqvae.py:141, is deterministic on its CPU path, float atomics are not) ----------------------
+ * embed_sum accumulated in 64-bit fixed point: x * 2^s with 2^s * max|x| <= 2^38.  Integer addition is associative,
+ * so the sums are bit-reproducible from run to run and for any sharding of the tokens (all-reduce them as int64),
+ * and they are the exact sums of the quantised inputs, rounded once in t5vq_ema_embed_fixed_f32.
+ *   t5vq_max_norm_f32:        max_xx_bits[0] = bit image of max_i xx[i]  (a token-sharded caller all-reduces it with
+ *                             MAX, as int32, so that every rank uses the same scale)
+ *   t5vq_embed_sum_fixed_f32: embed_sum[k - stats_begin, :] = sum_{i : idx_i = k} round(x_i * 2^s)   (int64 [.,D],
+ *                             zeroed by the call; N < 2^24, D <= 1024)
+ *   t5vq_ema_embed_fixed_f32: t5vq_ema_embed_f32 with dw = float(embed_sum * 2^-s). */
+int t5vq_max_norm_f32(const float* xx, int64_t N, int32_t* max_xx_bits, t5vq_stream_t stream);
+int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t* max_xx_bits, int64_t N, int64_t K,
+                             int64_t D, int64_t stats_begin, int64_t stats_count, int64_t* embed_sum,
+                             t5vq_stream_t stream);
+int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
+                             const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
+                             t5vq_stream_t stream);
+
 /* Gradient of the straight-through output and the MSE commitment term with respect to the inputs:
  *   grad_x = g_out - diff * (g_loss[0] * coef),  diff = q - x,  coef = commitment_cost * 2 / (N*D)
  * (autograd of vqvae/vqvae.py:148,157,160 and :55,69,71).  g_out or g_loss may be NULL (= 0). */

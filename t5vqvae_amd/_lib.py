@@ -31,6 +31,9 @@ SIGNATURES = {
     "t5vq_ema_cluster_f32": (c_int, [P, P, P, I64, I64, c_float, c_float, c_float, c_float, c_float, c_float,
                                      c_int, c_int, P, P]),
     "t5vq_ema_embed_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P]),
+    "t5vq_max_norm_f32": (c_int, [P, I64, P, P]),
+    "t5vq_embed_sum_fixed_f32": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P]),
+    "t5vq_ema_embed_fixed_f32": (c_int, [P, P, P, P, P, I64, I64, c_float, c_float, P]),
     "t5vq_ste_backward_f32": (c_int, [P, P, P, c_float, I64, P, P]),
     "t5vq_scatter_rows_f32": (c_int, [P, P, P, c_float, I64, I64, I64, P, P]),
     "t5vq_cosine_backward_f32": (c_int, [P, P, P, P, c_float, c_float, I64, I64, P, P, P]),

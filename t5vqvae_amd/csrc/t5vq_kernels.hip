@@ -1157,6 +1157,113 @@ __global__ __launch_bounds__(256) void rmsnorm_gamma_reduce_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Order-independent EMA statistics (opt-in): embed_sum accumulated in 64-bit fixed point.  Integer addition is
+// associative, so the result does not depend on the order in which workgroups (or GPUs: the all-reduce is an
+// integer SUM) arrive -- bit-reproducible from run to run and for any number of ranks; and it is the EXACT sum of
+// the quantised inputs, rounded once when converted back.  Fixed point: x * 2^s with 2^s * max|x| <= 2^38 (38
+// fractional bits relative to the largest input magnitude; up to 2^24 tokens per code fit 63 bits).  max|x| is
+// bounded by sqrt(max_i |x_i|^2), taken from the row norms.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_norm_kernel(const float* __restrict__ xx, long long n,
+                                                       int* __restrict__ max_bits) {   // *max_bits zeroed before
+    float m = 0.f;
+    for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < n;
+         i += static_cast<long long>(gridDim.x) * 256)
+        m = fmaxf(m, xx[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_int(m));   // xx >= 0: int order = float order
+}
+
+__device__ __forceinline__ int fixed_shift(int max_xx_bits) {   // s with 2^s * sqrt(max xx) <= 2^38
+    const int e2 = ((max_xx_bits >> 23) & 0xFF) - 127;            // floor(log2(max xx)); max|x| < 2^ceil((e2+1)/2)
+    int s = 38 - ((e2 + 2) >> 1);
+    return s > 1000 ? 1000 : (s < -1000 ? -1000 : s);
+}
+
+template <int NCH, int TOK>
+__global__ __launch_bounds__(256) void embed_sum_fixed_kernel(const float* __restrict__ x,
+                                                              const long long* __restrict__ keys, int N, int K, int D,
+                                                              const int* __restrict__ max_xx_bits, int stats_begin,
+                                                              int stats_count, long long* __restrict__ embed_sum) {
+    extern __shared__ __attribute__((aligned(16))) long long lbuf[];  // [4 waves][NCH*256] transposition rows
+    __shared__ int s_code[TOK];
+    __shared__ unsigned long long s_gmask[TOK];
+    __shared__ int s_gcode[TOK];
+    __shared__ int s_ngroups;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok0 = blockIdx.x * TOK;
+    const int n_here = min(TOK, N - tok0);
+    if (tid < TOK) {
+        int code = -1;
+        if (tid < n_here) {
+            code = key_index(keys[tok0 + tid]);
+            code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
+        }
+        s_code[tid] = code;
+    }
+    __syncthreads();
+    if (wave == 0) build_groups<TOK>(s_code, s_gmask, s_gcode, &s_ngroups, lane, nullptr, 0, 0);
+    __syncthreads();
+    const int n_groups = s_ngroups;
+    const double scale = ldexp(1.0, fixed_shift(*max_xx_bits));
+    long long* trow = lbuf + wave * (NCH * 256);
+    for (int g = wave; g < n_groups; g += 4) {
+        const int scode = __builtin_amdgcn_readfirstlane(s_gcode[g]) - stats_begin;
+        if (scode < 0 || scode >= stats_count) continue;
+        unsigned long long m = s_gmask[g];
+        long long sum[NCH * 4];
+#pragma unroll
+        for (int j = 0; j < NCH * 4; ++j) sum[j] = 0;
+        while (m) {
+            const int t = __ffsll(static_cast<long long>(m)) - 1;
+            m &= m - 1;
+            const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<size_t>(tok0 + t) * D);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c4 = j * 64 + lane;
+                if (c4 * 4 < D) {
+                    const f32x4 v = xr[c4];
+                    sum[4 * j + 0] += __double2ll_rn(static_cast<double>(v.x) * scale);
+                    sum[4 * j + 1] += __double2ll_rn(static_cast<double>(v.y) * scale);
+                    sum[4 * j + 2] += __double2ll_rn(static_cast<double>(v.z) * scale);
+                    sum[4 * j + 3] += __double2ll_rn(static_cast<double>(v.w) * scale);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) trow[(j * 64 + lane) * 4 + c] = sum[4 * j + c];
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(embed_sum) + static_cast<size_t>(scode) * D;
+#pragma unroll
+        for (int mcol = 0; mcol < NCH * 4; ++mcol) {
+            const int col = mcol * 64 + lane;
+            if (col < D) atomicAdd(dst + col, static_cast<unsigned long long>(trow[col]));
+        }
+    }
+}
+
+// K4b for the fixed-point statistics: dw = the exact sum, rounded once
+__global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
+                                                              const long long* __restrict__ dw,
+                                                              const int* __restrict__ max_xx_bits,
+                                                              const float* __restrict__ cs, int K, int D, float decay,
+                                                              float omd) {
+    const int lane = threadIdx.x & 63;
+    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= K) return;
+    const double inv = ldexp(1.0, -fixed_shift(*max_xx_bits));
+    const float c = cs[row];
+    for (int i = lane; i < D; i += 64) {
+        const float b = static_cast<float>(static_cast<double>(dw[row * D + i]) * inv);
+        const float v = __fadd_rn(__fmul_rn(ema_w[row * D + i], decay), __fmul_rn(omd, b));
+        ema_w[row * D + i] = v;
+        w[row * D + i] = __fdiv_rn(v, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward helpers
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ste_backward_kernel(const float* __restrict__ g_out,
@@ -1674,6 +1781,69 @@ int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const flo
     hipLaunchKernelGGL(ema_embed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),
                        static_cast<int>(D), decay, one_minus_decay);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_max_norm_f32(const float* xx, int64_t N, int32_t* max_xx_bits, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(xx && max_xx_bits && N > 0, "null pointer or empty input");
+    T5VQ_CHECK_HIP(hipMemsetAsync(max_xx_bits, 0, 4, stream));
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(max_norm_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, xx,
+                       static_cast<long long>(N), max_xx_bits);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t* max_xx_bits, int64_t N, int64_t K,
+                             int64_t D, int64_t stats_begin, int64_t stats_count, int64_t* embed_sum,
+                             t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(x && keys && max_xx_bits && embed_sum, "null pointer");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 24) && K < (1LL << 31), "N must be below 2^24, K below 2^31");
+    T5VQ_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x), "D % 4 and alignment");
+    T5VQ_REQUIRE(stats_begin >= 0 && stats_count >= 0 && stats_begin + stats_count <= K, "stats slice outside [0,K)");
+    const int nch = pick_nch(D);
+    T5VQ_REQUIRE(nch > 0 && nch <= 4, "D > 1024 is not supported by the fixed-point statistics");
+    if (stats_count == 0) return T5VQ_OK;
+    T5VQ_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(stats_count) * D * 8, stream));
+    const int tok = gs_tok(N);
+    const dim3 grid(static_cast<unsigned>((N + tok - 1) / tok));
+    const size_t lds = static_cast<size_t>(4) * nch * 256 * 8;
+    const long long* kp = reinterpret_cast<const long long*>(keys);
+    long long* ep = reinterpret_cast<long long*>(embed_sum);
+#define T5VQ_FX(NCH_, TOK_)                                                                                      \
+    hipLaunchKernelGGL((embed_sum_fixed_kernel<NCH_, TOK_>), grid, dim3(256), lds, stream, x, kp, static_cast<int>(N), \
+                       static_cast<int>(K), static_cast<int>(D), max_xx_bits, static_cast<int>(stats_begin),        \
+                       static_cast<int>(stats_count), ep)
+#define T5VQ_FX_T(NCH_)                      \
+    if (tok == GS_TOK_SMALL) {               \
+        T5VQ_FX(NCH_, GS_TOK_SMALL);         \
+    } else {                                 \
+        T5VQ_FX(NCH_, GS_TOK);               \
+    }
+    switch (nch) {
+        case 1: T5VQ_FX_T(1); break;
+        case 2: T5VQ_FX_T(2); break;
+        case 3: T5VQ_FX_T(3); break;
+        default: T5VQ_FX_T(4); break;
+    }
+#undef T5VQ_FX_T
+#undef T5VQ_FX
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
+                             const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
+                             t5vq_stream_t stream) {
+    T5VQ_REQUIRE(ema_w && w && embed_sum && max_xx_bits && cluster_size, "null pointer");
+    T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0, "K, D out of range");
+    hipLaunchKernelGGL(ema_embed_fixed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ema_w, w, reinterpret_cast<const long long*>(embed_sum),
+                       max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }

@@ -330,6 +330,42 @@ def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: 
                                           one_minus_decay, _stream(w)), "ema_embed")
 
 
+def max_norm(xx):
+    """int32[1]: bit image of max(xx) -- the scale source of the fixed-point statistics (t5vq_max_norm_f32)."""
+    lib = _lib.load()
+    _need(xx, "xx", ndim=1)
+    out = torch.empty(1, dtype=torch.int32, device=xx.device)
+    with torch.cuda.device(xx.device):
+        _lib.check(lib.t5vq_max_norm_f32(_p(xx), xx.shape[0], _p(out), _stream(xx)), "max_norm")
+    return out
+
+
+def embed_sum_fixed(x, keys, max_bits, k: int, stats_begin: int = 0, stats_count: Optional[int] = None):
+    """int64 [stats_count, D]: order-independent fixed-point sums of the inputs per code (t5vq_embed_sum_fixed_f32)."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(keys, "keys", torch.int64, 1), _need(max_bits, "max_bits", torch.int32)
+    n, d = x.shape
+    if stats_count is None:
+        stats_count = k - stats_begin
+    out = torch.empty(stats_count, d, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_embed_sum_fixed_f32(_p(x), _p(keys), _p(max_bits), n, k, d, stats_begin, stats_count,
+                                                _p(out), _stream(x)), "embed_sum_fixed")
+    return out
+
+
+def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay: float, one_minus_decay: float):
+    lib = _lib.load()
+    _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum_i64, "embed_sum", torch.int64)
+    _need(max_bits, "max_bits", torch.int32), _need(cluster_size, "cs")
+    k, d = ema_w.shape
+    if embed_sum_i64.numel() != k * d:
+        raise RuntimeError("ema_embed_fixed: embed_sum must be [K, D]")
+    with torch.cuda.device(w.device):
+        _lib.check(lib.t5vq_ema_embed_fixed_f32(_p(ema_w), _p(w), _p(embed_sum_i64), _p(max_bits), _p(cluster_size), k,
+                                                d, decay, one_minus_decay, _stream(w)), "ema_embed_fixed")
+
+
 def ste_backward(g_out, diff, g_loss, coef: float):
     lib = _lib.load()
     _need(diff, "diff")

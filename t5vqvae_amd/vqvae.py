@@ -123,6 +123,10 @@ class _QuantizerBase(nn.Module):
     search = "auto"
     filter_min_work = 1 << 24    # N*K below which the scan is faster (C2: 2e6 -> scan; C1: 2.9e7 -> filter)
     filter_backoff_calls = 32    # calls to stay on the scan after a call with > 1/8 of the tokens unsettled
+    # EMA statistics.  False: embed_sum by fp32 atomics (fastest; last bits depend on arrival order).  True: 64-bit
+    # fixed-point sums (t5vq_embed_sum_fixed_f32): bit-reproducible from run to run and for any token sharding, and
+    # exact up to one final rounding; costs one more pass over x.
+    deterministic = False
     index_mode = "reference"     # disentangled mode: "reference" = slice-relative indices used as rows (the
     #                              reference's behaviour, vqvae/vqvae.py:116-119) | "absolute" = start + argmin
 
@@ -209,9 +213,10 @@ class _QuantizerBase(nn.Module):
 
         # one contiguous statistics buffer: [embed_sum K*D | counts K | loss_sum 1 | pad] -- the unit that a
         # token-sharded run all-reduces in ONE collective (sharded.py)
-        kd = k * d if update else 0
+        fixed = update and self.deterministic
+        kd = k * d if (update and not fixed) else 0
         stats = torch.empty(kd + k + 4, dtype=torch.float32, device=dev)
-        embed_sum = stats[:kd].view(k, d) if update else None
+        embed_sum = stats[:kd].view(k, d) if kd else None
         counts = stats[kd:kd + k]
         loss_sum = stats[kd + k:kd + k + 1]
         ste = torch.empty_like(x)
@@ -233,20 +238,39 @@ class _QuantizerBase(nn.Module):
 
         n_total = n
         batch = plan.batch
+        world = 1
         if plan.group is not None:
             import torch.distributed as dist
-            dist.all_reduce(stats[:kd + k + 1], op=dist.ReduceOp.SUM, group=plan.group)
             world = dist.get_world_size(plan.group)
             n_total = plan.world_tokens if plan.world_tokens else n * world
             batch = batch * world
+        esum = max_bits = None
+        if fixed:
+            # order-independent statistics: every rank quantises with the same scale (global max norm), the int64
+            # sums add exactly in any order
+            xx = plan.xx if plan.xx is not None else ops.row_sqnorms(x, None)[0]
+            max_bits = ops.max_norm(xx)
+            if plan.group is not None:
+                dist.all_reduce(max_bits, op=dist.ReduceOp.MAX, group=plan.group)
+            esum = ops.embed_sum_fixed(x, idx, max_bits, k)      # idx doubles as keys (index = low word)
+            if plan.group is not None:
+                dist.all_reduce(esum, op=dist.ReduceOp.SUM, group=plan.group)
+        if plan.group is not None:
+            dist.all_reduce(stats[:kd + k + 1], op=dist.ReduceOp.SUM, group=plan.group)
 
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
         denom = float(n_total * d) if mse else float(batch)
         # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)
-        ops.ema_finalize(self._ema_cluster_size if update else None, self._ema_w.data if update else None,
-                         self._embedding.weight.data if update else None, counts, embed_sum, loss_sum, n_total,
-                         denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema, update,
-                         scalars)
+        if fixed:
+            ops.ema_cluster(self._ema_cluster_size, counts, loss_sum, k, n_total, denom, plan.decay, 1 - plan.decay,
+                            plan.eps, k * plan.eps, plan.cc, not plan.ema, 1, scalars)
+            ops.ema_embed_fixed(self._ema_w.data, self._embedding.weight.data, esum, max_bits,
+                                self._ema_cluster_size, plan.decay, 1 - plan.decay)
+        else:
+            ops.ema_finalize(self._ema_cluster_size if update else None, self._ema_w.data if update else None,
+                             self._embedding.weight.data if update else None, counts, embed_sum, loss_sum, n_total,
+                             denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema, update,
+                             scalars)
         return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q,
                 "dims": (n_total, d, k, batch)}
 

@@ -185,6 +185,29 @@ def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay):
     w.copy_(ema_w / cluster_size.unsqueeze(1))
 
 
+def _fixed_shift(max_bits):
+    e2 = ((int(max_bits[0]) >> 23) & 0xFF) - 127
+    return 38 - ((e2 + 2) >> 1)
+
+
+def max_norm(xx):
+    return xx.max().reshape(1).view(torch.int32).clone()
+
+
+def embed_sum_fixed(x, keys, max_bits, k, stats_begin=0, stats_count=None):
+    if stats_count is None:
+        stats_count = k - stats_begin
+    i = (keys & 0xFFFFFFFF).clamp(0, k - 1) - stats_begin
+    inside = (i >= 0) & (i < stats_count)
+    q = torch.round(x.double() * 2.0 ** _fixed_shift(max_bits)).to(torch.int64)
+    return torch.zeros(stats_count, x.shape[1], dtype=torch.int64).index_add_(0, i[inside], q[inside])
+
+
+def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay, one_minus_decay):
+    dw = (embed_sum_i64.double() * 2.0 ** -_fixed_shift(max_bits)).float()
+    ema_embed(ema_w, w, dw, cluster_size, decay, one_minus_decay)
+
+
 def ste_backward(g_out, diff, g_loss, coef):
     s = (g_loss * coef) if g_loss is not None else 0.0
     g = -diff * s

@@ -416,3 +416,49 @@ def test_index_mode_absolute_vs_oracle(n):
                                disentanglement=True, indices=idx)
     assert rel(q, o.quantized) <= TOL and rel(lo, o.loss) <= TOL and rel(ppl, o.perplexity) <= TOL
     assert torch.equal(m.get_indices(x.cuda(), srl.cuda()).squeeze(1).cpu(), idx)
+
+
+def test_deterministic_statistics_are_order_independent_and_exact():
+    """module.deterministic = True: EMA buffers bit-identical from run to run, bit-identical whether the statistics are
+    formed in one piece or as the integer sum of two token shards, and within 1e-6 of the oracle (the fixed-point sum
+    is the exact sum rounded once; the oracle's fp32 index_add carries accumulation error)."""
+    from t5vqvae_amd import VectorQuantizerEMA, ops
+    n, k, d = 6000, 300, 768
+    w, ew = synth.normal((k, d), 111, 0), synth.normal((k, d), 111, 1)
+    xs = [synth.normal((6, n // 6, d), 112, t) * (1.0 + 3.0 * t) for t in range(3)]
+
+    def run():
+        m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda().train()
+        with torch.no_grad():
+            m._embedding.weight.copy_(w), m._ema_w.copy_(ew)
+        m.encodings, m.deterministic = "indices", True
+        for x in xs:
+            m(x.cuda())
+        return m
+    a, b = run(), run()
+    for name, t in a.state_dict().items():
+        assert torch.equal(t, b.state_dict()[name]), name
+    st = vo.VQState(w.clone(), ew.clone(), torch.zeros(k))
+    for x in xs:
+        vo.algorithmic_forward(st, x, ema=True, training=True, commitment_cost=0.25)
+    assert rel(a._ema_w.data, st.ema_w) <= 1e-6 and rel(a._ema_cluster_size, st.cluster_size) <= 1e-6
+    # shards add exactly
+    flat = xs[0].cuda().view(-1, d)
+    wq = w.cuda()
+    xx, ee = ops.row_sqnorms(flat, wq)
+    keys = ops.dist_argmin(flat, wq, xx, ee)
+    mb = ops.max_norm(xx)
+    full = ops.embed_sum_fixed(flat, keys, mb, k)
+    h = n // 2 + 77
+    parts = ops.embed_sum_fixed(flat[:h].contiguous(), keys[:h].contiguous(), mb, k) \
+        + ops.embed_sum_fixed(flat[h:].contiguous(), keys[h:].contiguous(), mb, k)
+    assert torch.equal(full, parts)
+    idx = (keys & 0xFFFFFFFF).cpu()
+    exact = torch.zeros(k, d, dtype=torch.float64).index_add_(0, idx, xs[0].view(-1, d).double())
+    shift = 38 - ((((int(mb) >> 23) & 0xFF) - 127 + 2) >> 1)
+    got = full.cpu().double() * 2.0 ** -shift
+    assert float((got - exact).abs().max()) <= n * 2.0 ** -shift          # each term rounded to 2^-shift once
+    assert rel(got, exact) < 1e-9
+    # slices for code-sharded codebooks
+    sl = ops.embed_sum_fixed(flat, keys, mb, k, stats_begin=100, stats_count=50)
+    assert torch.equal(sl, full[100:150])

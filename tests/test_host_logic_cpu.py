@@ -79,11 +79,12 @@ def _reference_run(steps, roles=None, training=True):
     return st, outs
 
 
-def _token_sharded_worker(rank, world, port, q):
+def _token_sharded_worker(rank, world, port, q, deterministic=False):
     _init(rank, world, port)
     from t5vqvae_amd import VectorQuantizerEMA
     from t5vqvae_amd.sharded import shard_tokens, broadcast_state
     m = VectorQuantizerEMA(K, D, 0.25, decay=0.99)
+    m.deterministic = deterministic
     with torch.no_grad():
         if rank == 0:
             m._embedding.weight.copy_(synth.normal((K, D), 1, 0))
@@ -113,6 +114,19 @@ def _token_sharded_worker(rank, world, port, q):
         other = [torch.empty_like(tns) for _ in range(world)]
         dist.all_gather(other, tns)
         assert all(torch.equal(o_, other[0]) for o_ in other)
+    if deterministic:
+        # order-independent statistics: the two-rank result is BIT-IDENTICAL to one process on the whole batch
+        _patch()
+        single = VectorQuantizerEMA(K, D, 0.25, decay=0.99)
+        single.deterministic = True
+        with torch.no_grad():
+            single._embedding.weight.copy_(synth.normal((K, D), 1, 0))
+            single._ema_w.copy_(synth.normal((K, D), 1, 1))
+        single.train()
+        for t in range(2):
+            single(synth.normal((4, N // 4, D), 2, t))
+        for name, tns in m.state_dict().items():
+            assert torch.equal(tns, single.state_dict()[name]), name
     q.put((rank, max(errs)))
     dist.destroy_process_group()
 
@@ -161,8 +175,9 @@ def _run(worker, *args):
     assert max(res.values()) <= TOL, res
 
 
-def test_token_sharded_equals_single_process_gloo():
-    _run(_token_sharded_worker)
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_token_sharded_equals_single_process_gloo(deterministic):
+    _run(_token_sharded_worker, deterministic)
 
 
 @pytest.mark.parametrize("roles,training", [(None, True), (None, False),
