@@ -123,8 +123,9 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         keys = self._global_keys(x, w_local, ranges)
         w_full = self._full_codebook(w_local)
 
+        fixed = update and self.deterministic      # order-independent fixed-point sums (vqvae._QuantizerBase)
         counts = torch.empty(kl, dtype=torch.float32, device=dev)
-        embed_sum = torch.empty(kl, d, dtype=torch.float32, device=dev) if update else None
+        embed_sum = torch.empty(kl, d, dtype=torch.float32, device=dev) if (update and not fixed) else None
         partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
         loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         ste = torch.empty_like(x)
@@ -142,7 +143,12 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         ops.ema_cluster(cs, *args, 2, scalars)                                   # local partial sums
         dist.all_reduce(scalars[1:3], op=dist.ReduceOp.SUM, group=self.group)    # entropy, sum(cluster_size)
         ops.ema_cluster(cs, *args, 3, scalars)                                   # smoothing + perplexity
-        if update:
+        if fixed:
+            max_bits = ops.max_norm(ops.row_sqnorms(x, None)[0])                 # tokens are replicated: same scale
+            esum = ops.embed_sum_fixed(x, idx, max_bits, k, stats_begin=self.code_begin, stats_count=kl)
+            ops.ema_embed_fixed(self._ema_w.data, self._embedding.weight.data, esum, max_bits,
+                                self._ema_cluster_size, plan.decay, 1 - plan.decay)
+        elif update:
             ops.ema_embed(self._ema_w.data, self._embedding.weight.data, embed_sum, self._ema_cluster_size,
                           plan.decay, 1 - plan.decay)
         return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q, "dims": (n, d, k, plan.batch)}

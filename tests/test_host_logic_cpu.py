@@ -131,10 +131,11 @@ def _token_sharded_worker(rank, world, port, q, deterministic=False):
     dist.destroy_process_group()
 
 
-def _code_sharded_worker(rank, world, port, q, roles, training):
+def _code_sharded_worker(rank, world, port, q, roles, training, deterministic=False):
     _init(rank, world, port)
     from t5vqvae_amd.sharded import CodeShardedVectorQuantizerEMA
     m = CodeShardedVectorQuantizerEMA(K, D, 0.25, decay=0.99, disentanglement=roles is not None)
+    m.deterministic = deterministic
     m.load_full_state_dict({"_embedding.weight": synth.normal((K, D), 1, 0), "_ema_w": synth.normal((K, D), 1, 1),
                             "_ema_cluster_size": torch.zeros(K)})
     m.train(training)
@@ -156,6 +157,20 @@ def _code_sharded_worker(rank, world, port, q, roles, training):
     full = m.full_state_dict()
     errs += [rel(full["_ema_cluster_size"], st.cluster_size), rel(full["_ema_w"], st.ema_w),
              rel(full["_embedding.weight"], st.weight)]
+    if deterministic:          # fixed-point statistics: the sharded _ema_w is BIT-IDENTICAL to the unsharded one (the
+        # codebook itself also divides by cluster sizes whose normaliser is reduced across ranks: equal to rounding)
+        from t5vqvae_amd import VectorQuantizerEMA
+        single = VectorQuantizerEMA(K, D, 0.25, decay=0.99, disentanglement=roles is not None)
+        single.deterministic = True
+        with torch.no_grad():
+            single._embedding.weight.copy_(synth.normal((K, D), 1, 0))
+            single._ema_w.copy_(synth.normal((K, D), 1, 1))
+        single.train(training)
+        for t in range(2):
+            single(synth.normal((4, N // 4, D), 2, t),
+                   synth.role_ranges(N, roles, 3, t).view(4, N // 4, 2) if roles else None)
+        assert torch.equal(full["_ema_w"], single.state_dict()["_ema_w"])
+        assert rel(full["_embedding.weight"], single.state_dict()["_embedding.weight"]) <= 1e-6
     q.put((rank, max(errs)))
     dist.destroy_process_group()
 
@@ -185,6 +200,10 @@ def test_token_sharded_equals_single_process_gloo(deterministic):
                                             ([(0, 50), (50, 200), (120, 256), (3, 5)], True)])  # straddling
 def test_code_sharded_equals_single_process_gloo(roles, training):
     _run(_code_sharded_worker, roles, training)
+
+
+def test_code_sharded_deterministic_is_bit_identical_to_unsharded_gloo():
+    _run(_code_sharded_worker, [(0, 50), (50, 200), (120, 256), (3, 5)], True, True)
 
 
 def test_encoder_tail_host_logic_and_autograd(monkeypatch):
