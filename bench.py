@@ -154,6 +154,13 @@ def other_search(mod, x, w, ema_w, cs, args, n, k, d):
             "pipe": "fp16 MFMA filter (2500 TF) + fp32 decision" if other == "filter" else "fp32 MFMA (157.3 TF)"}
 
 
+def step_bytes(n, k, d, update):
+    b = 4.0 * (n * d + k * d + n * d) + 8.0 * n + 4.0 * k
+    if update:
+        b += 4.0 * n * d + 12.0 * k * d + 12.0 * k
+    return b
+
+
 def measured_traffic(workload):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json; counters cannot be read from inside this process)."""
@@ -271,6 +278,9 @@ def main():
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
                          "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k},
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
+            # SURVEY 8d algorithmic bytes of the whole step (fwd: x, W, q, idx, ee; EMA: x again, ema_w r/w, W w)
+            "step_algorithmic_bytes": step_bytes(n, k, d, update),
+            "step_frac_of_hbm_roofline": step_bytes(n, k, d, update) / (PEAK_HBM_GBS * 1e9) / (ms_per_step * 1e-3),
         }
     if rank == 0 and world == 1:
         result["config"]["search"] = args.search
