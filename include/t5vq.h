@@ -97,11 +97,23 @@ int t5vq_distances_f32(const float* x, const float* w, const float* xx, const fl
  *                    both only for stats_begin <= k < stats_begin + stats_count (the whole codebook:
  *                    0, K; a code shard keeps statistics for its own slice only)
  *   loss_partial[b] = per-workgroup sum of (q-x)^2 (MSE) or of 1 - cos(q_i, x_i) (COSINE, ATen
- *                    cosine_embedding_loss form, eps 1e-12); length t5vq_gather_blocks(N) (nullable) */
+ *                    cosine_embedding_loss form, eps 1e-12); length t5vq_gather_blocks(N) (nullable)
+ *   perm (nullable): the tokens in an order that puts equal codes next to each other (t5vq_order_by_code); a
+ *                    workgroup then flushes one partial row per run of equal codes instead of one per token
+ *                    Outputs stay in token order.  With perm, loss_partial holds one term per TOKEN (length N,
+ *                    indexed by token): which tokens share a workgroup then varies from run to run, and the
+ *                    loss must not. */
 int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
                           int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
                           int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
-                          float* loss_partial, t5vq_stream_t stream);
+                          float* loss_partial, const int32_t* perm, t5vq_stream_t stream);
+
+/* perm[0..N) = the token ids grouped by the code in their key (counting sort; the order inside a code is not
+ * specified) -- or the identity, when the histogram shows that grouping would not save the statistics kernel
+ * enough flushes to cover the sort (batches whose neighbouring tokens already share codes); decided on the
+ * device, no host read-back.  work: K + 2 int32 of scratch.  No reference counterpart (an ordering for
+ * t5vq_gather_stats_f32). */
+int t5vq_order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work, t5vq_stream_t stream);
 
 /* loss_sum[0] = sum of the n partials (fixed order, fp64 accumulation). */
 int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream);

@@ -26,7 +26,8 @@ SIGNATURES = {
     "t5vq_dist_argmin_f32": (c_int, [P, P, P, P, P, I64, I64, I64, I64, c_int, P, P]),
     "t5vq_unpack_keys": (c_int, [P, I64, P, P, P]),
     "t5vq_distances_f32": (c_int, [P, P, P, P, I64, I64, I64, P, P]),
-    "t5vq_gather_stats_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, P, P, P, I64, I64, P, P, P, P]),
+    "t5vq_gather_stats_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, P, P, P, I64, I64, P, P, P, P, P]),
+    "t5vq_order_by_code": (c_int, [P, I64, I64, P, P, P]),
     "t5vq_reduce_partials_f32": (c_int, [P, I64, P, P]),
     "t5vq_ema_cluster_f32": (c_int, [P, P, P, I64, I64, c_float, c_float, c_float, c_float, c_float, c_float,
                                      c_int, c_int, P, P]),

@@ -779,6 +779,104 @@ __global__ __launch_bounds__(256) void blend_argmin_kernel(const float* __restri
 // global_atomic_add_f32 wave-instruction covers 256 contiguous bytes.
 // Lane layout inside a row: float4 #(j*64 + lane), j < NCH  (NCH = ceil(D / 256)).
 // ------------------------------------------------------------------------------------------------
+// Tokens ordered by code (counting sort; order inside a code is arrival order): with it a workgroup of the
+// statistics kernel sees runs of equal codes and flushes one partial row per run instead of one per token --
+// at C3 (8 tokens per code, spread over the batch) 189 -> 104 us, the gap between the atomic roof and the HBM roof.
+// Whether that pays is decided ON THE DEVICE from the histogram pass: it also counts the (64-token block, code)
+// groups the plain walk would flush; the scan compares that with distinct codes + N/64, the ordered walk's
+// flushes, and the placement writes the identity when the difference would not cover the sort (clustered or
+// collapsed batches, where neighbours already share codes).  Lanes of a wave that hold the same code are
+// combined before any atomic, so a collapsed codebook does not serialise on one counter.
+__device__ __forceinline__ unsigned long long same_code_lanes(int code, bool valid, int* n_distinct) {
+    unsigned long long todo = __ballot(valid);
+    unsigned long long mine = 0;
+    int distinct = 0;
+    while (todo) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        const int c = __shfl(code, leader);
+        const unsigned long long m = __ballot(valid && code == c);
+        if (valid && code == c) mine = m;
+        todo &= ~m;
+        ++distinct;
+    }
+    *n_distinct = distinct;
+    return mine;
+}
+// work layout: [0, K) counters / cursors, [K] groups of the plain walk, [K+1] 1 = order the tokens, 0 = identity
+__global__ __launch_bounds__(256) void code_hist_kernel(const long long* __restrict__ keys, int N, int K,
+                                                        int* __restrict__ work) {
+    __shared__ int s_groups;
+    if (threadIdx.x == 0) s_groups = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < N;
+    int code = valid ? key_index(keys[i]) : 0;
+    code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
+    int distinct;
+    const unsigned long long m = same_code_lanes(code, valid, &distinct);
+    if (valid && __ffsll(static_cast<long long>(m)) - 1 == lane) atomicAdd(work + code, __popcll(m));
+    if (lane == 0) atomicAdd(&s_groups, distinct);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(work + K, s_groups);
+}
+__global__ __launch_bounds__(1024) void code_scan_kernel(int* __restrict__ work, int N, int K) {  // in place: exclusive scan
+    __shared__ int s_sum[1024];
+    __shared__ int s_used[16];
+    const int per = (K + 1023) / 1024;
+    const int b = threadIdx.x * per;
+    int local = 0, used = 0;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            const int c = work[b + i];
+            local += c;
+            used += c > 0;
+        }
+    s_sum[threadIdx.x] = local;
+    used = static_cast<int>(wave_sum(static_cast<float>(used)));   // <= 64 * per: exact in fp32
+    if ((threadIdx.x & 63) == 0) s_used[threadIdx.x >> 6] = used;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_sum[threadIdx.x] - local;
+    for (int i = 0; i < per; ++i)
+        if (b + i < K) {
+            const int c = work[b + i];
+            work[b + i] = run;
+            run += c;
+        }
+    if (threadIdx.x == 0) {
+        int codes_used = 0;
+        for (int i = 0; i < 16; ++i) codes_used += s_used[i];
+        const long long plain = work[K];
+        const long long ordered = codes_used + (N + 63) / 64;
+        work[K + 1] = (plain - ordered) * 4 > N ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void code_place_kernel(const long long* __restrict__ keys, int N, int K,
+                                                         int* __restrict__ work, int* __restrict__ perm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < N;
+    if (!work[K + 1]) {           // the same value for every thread of the grid
+        if (valid) perm[i] = i;
+        return;
+    }
+    int code = valid ? key_index(keys[i]) : 0;
+    code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
+    int distinct;
+    const unsigned long long m = same_code_lanes(code, valid, &distinct);
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    int base = 0;
+    if (valid && leader == lane) base = atomicAdd(work + code, __popcll(m));
+    base = __shfl(base, leader < 0 ? lane : leader);
+    if (valid) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
 constexpr int GS_TOK = 64;    // tokens per workgroup (large N)
 constexpr int GS_TOK_SMALL = 16;   // ... when N / 64 workgroups would leave most CUs idle
 constexpr int GS_SMALL_N = 32768;  // below this many tokens the small form is used (>= 2 workgroups per CU above)
@@ -813,9 +911,10 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const long long* __restrict__ keys, int N, int K,
     int D, float* __restrict__ out_ste, float* __restrict__ out_q, float* __restrict__ out_diff,
     long long* __restrict__ idx_out, int stats_begin, int stats_count, float* __restrict__ counts,
-    float* __restrict__ embed_sum, float* __restrict__ loss_partial) {
+    float* __restrict__ embed_sum, float* __restrict__ loss_partial, const int* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // [4 waves][NCH*256] transposition rows
     __shared__ int s_code[TOK];
+    __shared__ int s_tok[TOK];   // the workgroup's tokens: positions tok0.. of `perm` (tokens ordered by code), or tok0.. itself
     __shared__ unsigned long long s_gmask[TOK];
     __shared__ int s_gcode[TOK];
     __shared__ int s_ngroups;
@@ -828,13 +927,15 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
     const int n_here = min(TOK, N - tok0);
 
     if (tid < TOK) {
-        int code = -1;
+        int code = -1, real = 0;
         if (tid < n_here) {
-            code = key_index(keys[tok0 + tid]);
+            real = perm ? perm[tok0 + tid] : tok0 + tid;
+            code = key_index(keys[real]);
             code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
-            if (idx_out) idx_out[tok0 + tid] = code;
+            if (idx_out) idx_out[real] = code;
         }
         s_code[tid] = code;
+        s_tok[tid] = real;
     }
     __syncthreads();
     if (wave == 0) build_groups<TOK>(s_code, s_gmask, s_gcode, &s_ngroups, lane, counts, stats_begin, stats_count);
@@ -866,7 +967,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
         while (m) {
             const int t = __ffsll(static_cast<long long>(m)) - 1;
             m &= m - 1;
-            const size_t rowoff = static_cast<size_t>(tok0 + t) * D;
+            const size_t rowoff = static_cast<size_t>(s_tok[t]) * D;
             const f32x4* xr = reinterpret_cast<const f32x4*>(x + rowoff);
             f32x4 xv[NCH];
 #pragma unroll
@@ -875,6 +976,9 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
                 xv[j] = (c4 * 4 < D) ? xr[c4] : zero4;
             }
             float pd = 0.f, px = 0.f;
+            // ordered tokens: which tokens share a workgroup varies from run to run, so the loss is kept per TOKEN
+            // and summed in token order afterwards -- the loss stays bit-reproducible
+            float acc = perm ? 0.f : lsum;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c4 = j * 64 + lane;
@@ -888,10 +992,10 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
                     pd += q[j].x * xv[j].x + q[j].y * xv[j].y + q[j].z * xv[j].z + q[j].w * xv[j].w;
                     px += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
                 } else {
-                    lsum = fmaf(df.x, df.x, lsum);
-                    lsum = fmaf(df.y, df.y, lsum);
-                    lsum = fmaf(df.z, df.z, lsum);
-                    lsum = fmaf(df.w, df.w, lsum);
+                    acc = fmaf(df.x, df.x, acc);
+                    acc = fmaf(df.y, df.y, acc);
+                    acc = fmaf(df.z, df.z, acc);
+                    acc = fmaf(df.w, df.w, acc);
                 }
                 sum[j] += xv[j];
             }
@@ -899,7 +1003,17 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
                 pd = wave_sum(pd);
                 px = wave_sum(px);
                 const float den = sqrtf((qq + 1e-12f) * (px + 1e-12f));
-                if (lane == 0) lsum += 1.0f - pd / den;
+                const float term = 1.0f - pd / den;
+                if (perm) {
+                    if (lane == 0 && loss_partial) loss_partial[s_tok[t]] = term;
+                } else if (lane == 0) {
+                    lsum += term;
+                }
+            } else if (perm) {
+                acc = wave_sum(acc);
+                if (lane == 0 && loss_partial) loss_partial[s_tok[t]] = acc;
+            } else {
+                lsum = acc;
             }
         }
         const int scode = code - stats_begin;
@@ -915,7 +1029,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
             }
         }
     }
-    if (loss_partial) {
+    if (loss_partial && !perm) {
         lsum = wave_sum(lsum);
         if (lane == 0) s_red[wave] = lsum;
         __syncthreads();
@@ -923,15 +1037,27 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ p, long long n,
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ p, long long n,
                                                               float* __restrict__ out) {
-    __shared__ double s[4];
-    double acc = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) acc += static_cast<double>(p[i]);
-    acc = wave_sum_d(acc);
+    __shared__ double s[16];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent loads in flight; fixed order for a given n
+    long long i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        const float v0 = p[i], v1 = p[i + 1024], v2 = p[i + 2048], v3 = p[i + 3072];
+        a0 += static_cast<double>(v0);
+        a1 += static_cast<double>(v1);
+        a2 += static_cast<double>(v2);
+        a3 += static_cast<double>(v3);
+    }
+    for (; i < n; i += 1024) a0 += static_cast<double>(p[i]);
+    double acc = wave_sum_d((a0 + a1) + (a2 + a3));
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = static_cast<float>((s[0] + s[1]) + (s[2] + s[3]));
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += s[k];
+        out[0] = static_cast<float>(t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1690,7 +1816,7 @@ int t5vq_unpack_keys(const int64_t* keys, int64_t N, int64_t* idx, float* dmin, 
 static int launch_gather(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
-                         float* loss_partial, bool stats_zeroed, hipStream_t stream) {
+                         float* loss_partial, bool stats_zeroed, const int32_t* perm, hipStream_t stream) {
     T5VQ_REQUIRE(x && w && keys, "null input");
     T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
     T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
@@ -1715,7 +1841,8 @@ static int launch_gather(const float* x, const float* w, const int64_t* keys, in
 #define T5VQ_GS_T(NCH_, COS_, TOK_)                                                                                 \
     hipLaunchKernelGGL((gather_stats_kernel<NCH_, COS_, TOK_>), grid, dim3(256), lds, stream, x, w, kp,             \
                        static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), out_ste, out_q, out_diff, ip, \
-                       static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial)
+                       static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial, \
+                       perm)
 #define T5VQ_GS(NCH_, COS_)                                   \
     if (gs_tok(N) == GS_TOK_SMALL) {                          \
         T5VQ_GS_T(NCH_, COS_, GS_TOK_SMALL);                  \
@@ -1745,14 +1872,30 @@ static int launch_gather(const float* x, const float* w, const int64_t* keys, in
 int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
                           int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
                           int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
-                          float* loss_partial, t5vq_stream_t stream) {
+                          float* loss_partial, const int32_t* perm, t5vq_stream_t stream) {
     return launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, stats_begin, stats_count,
-                         counts, embed_sum, loss_partial, false, static_cast<hipStream_t>(stream));
+                         counts, embed_sum, loss_partial, false, perm, static_cast<hipStream_t>(stream));
+}
+
+int t5vq_order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work,
+                       t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(keys && perm && work, "null pointer");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
+    const long long* kp = reinterpret_cast<const long long*>(keys);
+    T5VQ_CHECK_HIP(hipMemsetAsync(work, 0, static_cast<size_t>(K + 2) * 4, stream));
+    const dim3 grid(static_cast<unsigned>((N + 255) / 256));
+    hipLaunchKernelGGL(code_hist_kernel, grid, dim3(256), 0, stream, kp, static_cast<int>(N), static_cast<int>(K), work);
+    hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), static_cast<int>(K));
+    hipLaunchKernelGGL(code_place_kernel, grid, dim3(256), 0, stream, kp, static_cast<int>(N), static_cast<int>(K), work,
+                       perm);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
 }
 
 int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream) {
     T5VQ_REQUIRE(partials && loss_sum && n >= 0, "null pointer or negative n");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partials,
                        static_cast<long long>(n), loss_sum);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
@@ -2019,13 +2162,15 @@ int t5vq_blend_argmin_f32(const float* dist_left, const float* dist_right, float
 namespace {
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 struct FwdWorkspace {
-    int64_t keys, xx, ee, partial, total;
+    int64_t keys, xx, ee, partial, perm, work, total;
     FwdWorkspace(int64_t N, int64_t K) {
         keys = 0;                                                   // int64 [N]
         xx = align_up(8 * N, 16);                                   // fp32 [N]
         ee = align_up(xx + 4 * N, 16);                              // fp32 [padded(K)], 16-byte aligned
-        partial = align_up(ee + 4 * t5vq_padded_codes(K), 16);      // fp32 [gather_blocks(N)]
-        total = align_up(partial + 4 * t5vq_gather_blocks(N), 256);
+        partial = align_up(ee + 4 * t5vq_padded_codes(K), 16);      // fp32 [gather_blocks(N)], [N] with ordered tokens
+        perm = align_up(partial + 4 * N, 16);                       // int32 [N]: tokens ordered by code
+        work = align_up(perm + 4 * N, 16);                          // int32 [K + 2]: counting-sort cursors
+        total = align_up(work + 4 * (K + 2), 256);
     }
 };
 }  // namespace
@@ -2035,7 +2180,8 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
     return FwdWorkspace(N, K).total;
 }
 
-// Four launches: [row norms + buffer preparation] -> [distance + argmin] -> [gather + statistics] -> [loss sum].
+// Launches: [row norms + buffer preparation] -> [distance + argmin] -> ([order tokens by code: 3 small launches],
+// training with N >= 32768) -> [gather + statistics] -> [loss sum].
 int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
                         int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
@@ -2066,10 +2212,17 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
     opts.keys_prefilled = true;
     rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream, opts);
     if (rc != T5VQ_OK) return rc;
+    const int32_t* perm = nullptr;
+    if (embed_sum && N >= GS_SMALL_N) {   // statistics wanted, enough tokens for the ordering to pay for itself
+        int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
+        rc = t5vq_order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        if (rc != T5VQ_OK) return rc;
+        perm = p;
+    }
     rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
-                       partial, true, stream);
+                       partial, true, perm, stream);
     if (rc != T5VQ_OK || !loss_sum) return rc;
-    return t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
+    return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
 }
 
 int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,

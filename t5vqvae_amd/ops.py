@@ -40,6 +40,9 @@ def padded_codes(k: int) -> int:
     return int(_lib.load().t5vq_padded_codes(k))
 
 
+ORDER_MIN_TOKENS = 32768    # tokens from which ordering them by code pays for itself (GS_SMALL_N in the kernels)
+
+
 def gather_blocks(n: int) -> int:
     return int(_lib.load().t5vq_gather_blocks(n))
 
@@ -182,8 +185,10 @@ def blend_argmin(dist_left, dist_right, weight_left: float, weight_right: float)
 
 
 def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, idx=None, counts=None,
-                 embed_sum=None, loss_partial=None, stats_begin: int = 0, stats_count: Optional[int] = None):
-    """Every output is optional and caller-allocated (None = not produced)."""
+                 embed_sum=None, loss_partial=None, stats_begin: int = 0, stats_count: Optional[int] = None,
+                 perm=None):
+    """Every output is optional and caller-allocated (None = not produced).  ``perm`` (order_by_code): walk the
+    tokens grouped by code; ``loss_partial`` then holds one term per token (length n) instead of one per workgroup."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(keys, "keys", torch.int64, 1)
     n, d = x.shape
@@ -192,17 +197,33 @@ def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, 
         stats_count = k - stats_begin
     for name, t, shape in (("ste", ste, (n, d)), ("q", q, (n, d)), ("diff", diff, (n, d)),
                            ("counts", counts, (stats_count,)), ("embed_sum", embed_sum, (stats_count, d)),
-                           ("loss_partial", loss_partial, (gather_blocks(n),))):
+                           ("loss_partial", loss_partial, (n if perm is not None else gather_blocks(n),))):
         if t is not None:
             _need(t, name)
             if t.numel() != int(torch.Size(shape).numel()):
                 raise RuntimeError(f"{name}: expected {shape}, got {tuple(t.shape)}")
     if idx is not None:
         _need(idx, "idx", torch.int64)
+    if perm is not None:
+        _need(perm, "perm", torch.int32, 1)
+        if perm.numel() != n:
+            raise RuntimeError(f"perm: expected {n} token ids, got {perm.numel()}")
     with torch.cuda.device(x.device):
         _lib.check(lib.t5vq_gather_stats_f32(_p(x), _p(w), _p(keys), n, k, d, LOSS_KINDS[loss], _p(ste), _p(q),
                                              _p(diff), _p(idx), stats_begin, stats_count, _p(counts),
-                                             _p(embed_sum), _p(loss_partial), _stream(x)), "gather_stats")
+                                             _p(embed_sum), _p(loss_partial), _p(perm), _stream(x)), "gather_stats")
+
+
+def order_by_code(keys, k: int):
+    """int32 [N]: the token ids grouped by the code in their key (t5vq_order_by_code), for gather_stats(perm=)."""
+    lib = _lib.load()
+    _need(keys, "keys", torch.int64, 1)
+    n = keys.numel()
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    work = torch.empty(k + 2, dtype=torch.int32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        _lib.check(lib.t5vq_order_by_code(_p(keys), n, k, _p(perm), _p(work), _stream(keys)), "order_by_code")
+    return perm
 
 
 def forward_workspace_bytes(n: int, k: int) -> int:

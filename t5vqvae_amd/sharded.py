@@ -126,14 +126,17 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         fixed = update and self.deterministic      # order-independent fixed-point sums (vqvae._QuantizerBase)
         counts = torch.empty(kl, dtype=torch.float32, device=dev)
         embed_sum = torch.empty(kl, d, dtype=torch.float32, device=dev) if (update and not fixed) else None
-        partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
+        perm = (ops.order_by_code(keys, w_full.shape[0])
+                if (embed_sum is not None and n >= ops.ORDER_MIN_TOKENS) else None)
+        partial = torch.empty(n if perm is not None else ops.gather_blocks(n), dtype=torch.float32, device=dev)
         loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         ste = torch.empty_like(x)
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         diff = torch.empty_like(x) if want_diff else None
         q = torch.empty_like(x) if want_q else None
         ops.gather_stats(x, w_full, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
-                         embed_sum=embed_sum, loss_partial=partial, stats_begin=self.code_begin, stats_count=kl)
+                         embed_sum=embed_sum, loss_partial=partial, stats_begin=self.code_begin, stats_count=kl,
+                         perm=perm)
         ops.reduce_partials(partial, loss_sum)       # tokens are replicated: the loss needs no reduction
 
         scalars = torch.empty(4, dtype=torch.float32, device=dev)

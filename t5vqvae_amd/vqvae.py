@@ -228,9 +228,11 @@ class _QuantizerBase(nn.Module):
             # role-bucketed search (permute, search, scatter back) or filtered search, then the fine-grained calls
             keys = self._absolute(self._nearest_keys(x, w, ranges, xx=plan.xx, exact_keys=False,
                                                      use_filter=use_filter), ranges)
-            partial = torch.empty(ops.gather_blocks(n), dtype=torch.float32, device=dev)
+            # embed_sum wanted and enough tokens: walk them grouped by code (one flush per run of equal codes)
+            perm = ops.order_by_code(keys, k) if (embed_sum is not None and n >= ops.ORDER_MIN_TOKENS) else None
+            partial = torch.empty(n if perm is not None else ops.gather_blocks(n), dtype=torch.float32, device=dev)
             ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
-                             embed_sum=embed_sum, loss_partial=partial)
+                             embed_sum=embed_sum, loss_partial=partial, perm=perm)
             ops.reduce_partials(partial, loss_sum)
         else:                                                    # the whole forward behind one host call
             ops.vq_forward(x, w, ranges, plan.loss, xx=plan.xx, ste=ste, q=q, diff=diff, idx=idx, counts=counts,

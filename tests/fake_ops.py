@@ -83,7 +83,7 @@ def distances(x, w, xx, ee):
 
 
 def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
-                 loss_partial=None, stats_begin=0, stats_count=None):
+                 loss_partial=None, stats_begin=0, stats_count=None, perm=None):
     n, d = x.shape
     k = w.shape[0]
     if stats_count is None:
@@ -110,9 +110,19 @@ def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=Non
             per = (df * df).sum(1)
         else:
             per = 1 - (qq * x).sum(1) / (((qq * qq).sum(1) + 1e-12) * ((x * x).sum(1) + 1e-12)).sqrt()
-        pad = torch.zeros(gather_blocks(n) * 64)
-        pad[:n] = per
-        loss_partial.copy_(pad.view(-1, 64).sum(1))
+        if perm is not None:
+            loss_partial.copy_(per)
+        else:
+            pad = torch.zeros(gather_blocks(n) * 64)
+            pad[:n] = per
+            loss_partial.copy_(pad.view(-1, 64).sum(1))
+
+
+ORDER_MIN_TOKENS = 32768
+
+
+def order_by_code(keys, k):
+    return torch.argsort((keys & 0xFFFFFFFF).clamp(0, k - 1), stable=True).to(torch.int32)
 
 
 def vq_forward(x, w, ranges, loss, *, xx=None, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,

@@ -38,9 +38,11 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.t5vq_row_sqnorms_f32(p, 4, p, p, 4, p, 6, None) == 1          # D % 4 != 0
     assert b"multiple of 4" in lib.t5vq_last_error()
     assert lib.t5vq_dist_argmin_f32(None, p, p, p, None, 4, 4, 8, 0, 0, p, None) == 1
-    assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 8, 7, None, None, None, None, 0, 4, None, None, None, None) == 1
+    assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 8, 7, None, None, None, None, 0, 4, None, None, None, None,
+                                     None) == 1
     assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 4096, 0, None, None, None, None, 0, 4, None, None, None,
-                                     None) == 1                               # D > 2048
+                                     None, None) == 1                               # D > 2048
+    assert lib.t5vq_order_by_code(p, 4, 4, None, p, None) == 1
     assert lib.t5vq_ema_cluster_f32(None, p, None, 4, 4, 1.0, .99, .01, 1e-5, 4e-5, .25, 0, 9, p, None) == 1
 
 

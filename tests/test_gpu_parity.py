@@ -132,6 +132,51 @@ def test_determinism_same_input_twice():
     assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
 
 
+@pytest.mark.parametrize("pattern", ["uniform", "hot21", "hot1", "runs"])
+@pytest.mark.parametrize("loss", ["mse", "cosine"])
+def test_ordered_tokens_give_the_same_statistics(pattern, loss):
+    """t5vq_order_by_code + gather_stats(perm=) against the plain walk: perm is a permutation grouped by code, every
+    per-token output and the counts are equal, embed_sum within fp32 summation-order noise, the loss (summed in
+    token order from per-token terms) reproducible bit for bit and within tolerance of the per-workgroup form."""
+    from t5vqvae_amd import ops
+    n, k, d = 40000, 1000, 768          # n not a multiple of 64, above ORDER_MIN_TOKENS
+    dev = torch.device("cuda", 0)
+    x = synth.normal((n, d), 41, 0, device=dev)
+    w = synth.normal((k, d), 41, 1, device=dev)
+    codes = {"uniform": synth.uniform_int(n, k, 41, 2, dev),
+             "hot21": synth.uniform_int(n, 21, 41, 3, dev) * 40,
+             "hot1": torch.full((n,), 7, dtype=torch.int64, device=dev),
+             "runs": synth.uniform_int(n, k, 41, 4, dev)[torch.arange(n, device=dev) // 5]}[pattern]
+    keys = codes.to(torch.int64) | (torch.arange(n, device=dev) << 32)       # some distance word; the index decides
+
+    def run(perm):
+        out = dict(ste=torch.empty_like(x), q=torch.empty_like(x), diff=torch.empty_like(x),
+                   idx=torch.empty(n, dtype=torch.int64, device=dev), counts=torch.empty(k, device=dev),
+                   embed_sum=torch.empty(k, d, device=dev))
+        part = torch.empty(n if perm is not None else ops.gather_blocks(n), device=dev)
+        ops.gather_stats(x, w, keys, loss, loss_partial=part, perm=perm, **out)
+        ls = torch.empty(1, device=dev)
+        ops.reduce_partials(part, ls)
+        return out, ls
+
+    perm = ops.order_by_code(keys, k)
+    assert torch.equal(torch.sort(perm.long())[0], torch.arange(n, device=dev))
+    pc = codes[perm.long()]
+    grouped = bool((pc[1:] >= pc[:-1]).all())
+    identity = torch.equal(perm.long(), torch.arange(n, device=dev))
+    # spread codes are grouped; batches whose neighbours already share codes are left in place (device-side decision)
+    assert (grouped and not identity) if pattern in ("uniform", "hot21") else identity
+    plain, ls_plain = run(None)
+    ordered, ls_ord = run(perm)
+    for name in ("ste", "q", "diff", "idx", "counts"):
+        assert torch.equal(plain[name], ordered[name]), name
+    assert rel(ordered["embed_sum"], plain["embed_sum"]) < 1e-6
+    assert rel(ls_ord, ls_plain) < 1e-6
+    perm2 = ops.order_by_code(keys, k)
+    _, ls_again = run(perm2)
+    assert torch.equal(ls_ord, ls_again)
+
+
 def test_full_size_c3_vs_oracle():
     """BASELINE config 3 (N=65536, K=8192) in the 'uniform' regime, whole step against the oracle."""
     n, k, d = 65536, 8192, 768

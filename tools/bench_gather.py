@@ -30,15 +30,24 @@ def main():
         part = torch.empty(ops.gather_blocks(n), device=dev)
         for name, codes in pats.items():
             keys = codes.to(torch.int64)          # distance word 0, index word = code
-            ts = []
+            ts, ts_sort, ts_ord = [], [], []
+            part_tok = torch.empty(n, device=dev)
             for i in range(25):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e2.record()
+                perm = ops.order_by_code(keys, k)
+                e3.record()
+                ops.gather_stats(x, w, keys, "mse", ste=ste, idx=idx, counts=counts, embed_sum=es,
+                                 loss_partial=part_tok, perm=perm)
                 e0.record()
                 ops.gather_stats(x, w, keys, "mse", ste=ste, idx=idx, counts=counts, embed_sum=es, loss_partial=part)
                 e1.record()
                 torch.cuda.synchronize()
                 if i >= 5:
                     ts.append(e0.elapsed_time(e1) * 1e3)
+                    ts_sort.append(e2.elapsed_time(e3) * 1e3)
+                    ts_ord.append(e3.elapsed_time(e0) * 1e3)
             assert torch.equal(idx, codes)
             ref = torch.bincount(codes, minlength=k).float()
             assert torch.equal(counts, ref)
@@ -48,7 +57,8 @@ def main():
                 assert err < 1e-5, err
             mb = (2 * n * d + (n * d if update else 0)) * 4 / 1e6
             print(f"N={n:7d} K={k:6d} {'fwd+stats' if update else 'fwd      '} {name:8s} "
-                  f"{statistics.median(ts):8.1f} us (min {min(ts):7.1f})  x+ste{'+atomics' if update else ''} {mb:7.1f} MB",
+                  f"{statistics.median(ts):8.1f} us (min {min(ts):7.1f}) | ordered: sort {statistics.median(ts_sort):6.1f} + "
+                  f"gather {statistics.median(ts_ord):7.1f} us  x+ste{'+atomics' if update else ''} {mb:7.1f} MB",
                   flush=True)
 
 
