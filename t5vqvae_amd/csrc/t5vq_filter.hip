@@ -34,7 +34,8 @@ constexpr int TOK_TILE = 256, CODE_TILE = 256, THREADS = 512;
 constexpr int BKC = 32;                 // 16-byte-aligned chunk of a row, in 4-byte units = 64 fp16
 constexpr int ROW = BKC + 4;            // LDS row stride (4-byte units): 144 B = 9 x 16 B, conflict-free b128 reads
 constexpr int X_IMG = TOK_TILE * ROW, W_IMG = CODE_TILE * ROW, STAGE = X_IMG + W_IMG;
-constexpr int LDS_BYTES = 2 * STAGE * 4;   // 147,456 B: one workgroup (8 waves) per CU
+constexpr int EPI = 3 * CODE_TILE;         // per code of the tile: |e|^2, |e|, inverse row scale (epilogue operands)
+constexpr int LDS_BYTES = (2 * STAGE + 2 * EPI) * 4;   // 147,456 + 6,144 B: one workgroup (8 waves) per CU
 constexpr int F4_PER_ROW = BKC / 4, ROWS_PER_PASS = THREADS / F4_PER_ROW, XV = TOK_TILE / ROWS_PER_PASS,
               WV = CODE_TILE / ROWS_PER_PASS, G = BKC / 8;
 constexpr int TB = 2, CB = 4;           // 32x32 blocks per wave: 64 tokens x 128 codes
@@ -43,6 +44,7 @@ __device__ __forceinline__ int order_image(float d) {
     const int b = __float_as_int(d);
     return b >= 0 ? b : (b ^ 0x7FFFFFFF);
 }
+__device__ __forceinline__ int order_image_inv(int b) { return b >= 0 ? b : (b ^ 0x7FFFFFFF); }   // an involution
 __device__ __forceinline__ long long pack_key(float d, int idx) {
     return (static_cast<long long>(order_image(d)) << 32) | static_cast<unsigned int>(idx);
 }
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           _Float16* __restrict__ wh, float* __restrict__ w_inv,
                                                           float* __restrict__ xx, float* __restrict__ ee,
                                                           long long kpad, float* __restrict__ se, int D,
-                                                          int* __restrict__ n_list) {
+                                                          int* __restrict__ n_list, int* __restrict__ tshare) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_list = 0;
     long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
     const bool is_w = row >= n_x;
     if (!is_w) {
         src = x + row * D; dst = xh + row * D; inv = x_inv + row; norm = xx + row;
+        if (lane == 0) tshare[row] = 0x7F800000;   // order image of +inf: no bound yet
     } else {
         row -= n_x;
         if (row >= kpad) return;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     const float* __restrict__ ee, const float* __restrict__ se, const float* __restrict__ x_inv,
     const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, int plain_map,
     float c2, float r, const long long* __restrict__ range, long long code_offset, float* __restrict__ ubuf,
-    float* __restrict__ lbuf, int* __restrict__ cbuf) {
+    float* __restrict__ lbuf, int* __restrict__ cbuf, int* __restrict__ tshare) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int wt = wave & 3, wc = wave >> 2;
@@ -277,6 +280,22 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
             for (int j = 0; j < WV; ++j)
                 *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
         };
+        // one quarter of a stage: written to LDS and re-issued behind the MFMAs of one 16-deep step
+        static_assert(XV == G && WV == G, "one x and one w register set per 16-deep step");
+        auto restage_part = [&](int j, int buf, int ct, int kc) {
+            float* xs = lds + buf * STAGE;
+            float* ws = xs + X_IMG;
+#ifndef T5VQ_AB_NOWRITE
+            *reinterpret_cast<f32x4*>(xs + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = sxv[j];
+            *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
+#endif
+#ifndef T5VQ_AB_NOLOAD
+            sxv[j] = *reinterpret_cast<const f32x4*>(xrow[j] + kc * BKC);
+            int c = (tile_begin + ct) * CODE_TILE + s_row + ROWS_PER_PASS * j;
+            if (c > K - 1) c = K - 1;
+            swv[j] = *reinterpret_cast<const f32x4*>(wb + static_cast<size_t>(c) * D2 + s_col + kc * BKC);
+#endif
+        };
 
         // Staging pipeline: ONE register set; the tile for step it+1 is written to LDS right AFTER the barrier that
         // ends step it-1 (its buffer is free from then on) and the loads for step it+2 are re-issued at once, so
@@ -296,16 +315,43 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                 for (int t = 0; t < CB; ++t)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[b][t][q] = 0.f;
+            // the epilogue's per-code operands go through LDS (two images, by tile parity): fetched during the first
+            // chunk of the tile, written during the second, read after the tile's last barrier -- read from global
+            // memory in the epilogue itself, every group of four codes waited a full L2 latency
+            float* epi = lds + 2 * STAGE + (ct & 1) * EPI;
+            float ep0 = 0.f, ep1 = 0.f;
+            int shared_u[TB];
             for (int kc = 0; kc < n_chunks; ++kc, ++it) {
+                if (kc == 0) {
+                    const int c = (tile_begin + ct) * CODE_TILE + (tid & (CODE_TILE - 1));
+                    if (tid < CODE_TILE) {
+                        ep0 = c < kpad ? ee[c] : __int_as_float(0x7F800000);
+                        ep1 = c < kpad ? se[c] : 0.f;
+                    } else {
+                        ep0 = c < kpad ? w_inv[c] : 1.f;
+                    }
+                }
+                if (kc == n_chunks - 1) {   // the bound other scanners of these tokens have published (any split, any CU)
+#pragma unroll
+                    for (int b = 0; b < TB; ++b) shared_u[b] = tshare[tok[b] < N ? tok[b] : N - 1];
+                }
+                if (kc == (n_chunks > 1 ? 1 : 0)) {
+                    if (tid < CODE_TILE) {
+                        epi[tid] = ep0;
+                        epi[CODE_TILE + tid] = ep1;
+                    } else {
+                        epi[2 * CODE_TILE + (tid & (CODE_TILE - 1))] = ep0;
+                    }
+                }
                 const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW + 4 * h;
                 const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW + 4 * h;
-                if (it + 1 < total) {
-                    store_stage((it + 1) & 1);      // step it+1, loaded during step it-1
-                    if (++lkc == n_chunks) { lkc = 0; ++lct; }
-                    if (it + 2 < total) load_stage(lct, lkc);
-                }
+                // step it+1 (loaded during step it-1) is written and step it+2 fetched in four parts, one behind each
+                // 16-deep step's MFMAs, without branches: past the end the last stage is fetched again and the
+                // write lands in a buffer nobody reads any more
+                if (it + 2 < total && ++lkc == n_chunks) { lkc = 0; ++lct; }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
+                    restage_part(g, (it + 1) & 1, lct, lkc);
                     f16x8 bf[TB], af[CB];
 #pragma unroll
                     for (int b = 0; b < TB; ++b)
@@ -321,44 +367,94 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                 }
                 __syncthreads();
             }
-            // epilogue: d~ = fl(fl(xx + ee) - 2 dot~), delta = c2 |x| |e| + r (xx + ee); U = d~ + delta, L = d~ - delta
-            const int code0 = (tile_begin + ct) * CODE_TILE + wc * 128 + 4 * h;
+            // epilogue: d~ = fl(fl(xx + ee) - 2 dot~), delta = c2 |x| |e| + r (xx + ee); U = d~ + delta, L = d~ - delta.
+            // Fast path, per (token, 32-code block): only d~ and its minimum are formed per element; the bounds use
+            // delta_max = delta at the largest |e| and |e|^2 of the block (rounding is monotone, so delta <= delta_max
+            // for each of its codes): umin <- min(umin, min d~ + delta_max) stays an upper bound of the true minimum,
+            // and no code of a group of four can be a candidate unless min4 d~ - delta_max <= umin.  Groups that pass
+            // (a few per cent) take the per-element path with each code's own delta, so the kept lower bounds are as
+            // tight as before.
+#ifdef T5VQ_AB_NOEPI
+            {
+                float keep = 0.f;
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+#pragma unroll
+                    for (int t = 0; t < CB; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) keep += acc[b][t][q];
+                if (keep == 12345.678f) sc[0].umin = keep;
+                continue;
+            }
+#endif
+            // Scanners of one token share their smallest upper bound through memory (order image, atomic min): each
+            // scanner alone would let every running minimum of ITS codes through as a candidate; with the shared
+            // bound only codes near the minimum over all codes seen so far by anyone pass.  Any published value is
+            // a valid upper bound of the token's true minimum, however stale.
+#pragma unroll
+            for (int b = 0; b < TB; ++b) sc[b].umin = fminf(sc[b].umin, __int_as_float(order_image_inv(shared_u[b])));
+            const int blk0 = (tile_begin + ct) * CODE_TILE + wc * 128;
+            const int code0 = blk0 + 4 * h;
 #pragma unroll
             for (int t = 0; t < CB; ++t) {
-                if (code0 + t * 32 >= kpad) break;   // |e|^2 is padded to 128 codes, the tile spans 256
+                if (blk0 + t * 32 >= kpad) break;   // |e|^2 is padded to 128 codes, the tile spans 256
+                const float* ep_e = epi + wc * 128 + t * 32;
+                const float* ep_s = ep_e + CODE_TILE;
+                const float* ep_i = ep_e + 2 * CODE_TILE;
+                float egmax = ep_e[l31], sgmax = ep_s[l31];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    egmax = fmaxf(egmax, __shfl_xor(egmax, o));   // padded codes: +inf -> delta_max = +inf -> slow path
+                    sgmax = fmaxf(sgmax, __shfl_xor(sgmax, o));
+                }
+                float dmax[TB];
+#pragma unroll
+                for (int b = 0; b < TB; ++b) dmax[b] = fmaf(csx[b], sgmax, r * (xv[b] + egmax));
+                const bool padded = !(egmax < __int_as_float(0x7F800000));   // a block with padded codes is looked at
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int cb = code0 + t * 32 + 8 * g4;
-                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(ee + cb);
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(se + cb);
-                    const f32x4 i4 = *reinterpret_cast<const f32x4*>(w_inv + cb);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(ep_e + 4 * h + 8 * g4);
+                    const f32x4 i4 = *reinterpret_cast<const f32x4*>(ep_i + 4 * h + 8 * g4);
 #pragma unroll
                     for (int b = 0; b < TB; ++b) {
-                        float lo[4];
-                        float lmin = __int_as_float(0x7F800000);
+                        float dm = __int_as_float(0x7F800000);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float s = xv[b] + e4[c];
-                            const float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);   // -2 dot~, rescaled exactly
+                            float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);   // -2 dot~, rescaled exactly
+                            if (RANGED) d = (cb + c >= ls[b] && cb + c < le[b]) ? d : __int_as_float(0x7F800000);
+                            dm = fminf(dm, d);
+                        }
+                        sc[b].umin = fminf(sc[b].umin, dm + dmax[b]);   // inf + inf = inf; never NaN (d~ > -inf)
+                        const float lm = dm - dmax[b];                  // inf - inf = NaN compares false: `padded`
+#ifdef T5VQ_AB_NOSLOW
+                        if (lm != 12345.678f) continue;
+#endif
+                        if (!__any(padded || (lm <= sc[b].umin && lm < sc[b].kl[KEEP - 1]))) continue;
+                        const f32x4 s4 = *reinterpret_cast<const f32x4*>(ep_s + 4 * h + 8 * g4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float s = xv[b] + e4[c];
+                            const float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);
                             const float delta = fmaf(csx[b], s4[c], r * s);
                             float up = d + delta;                        // padded codes: +inf
-                            lo[c] = d - delta;                           // padded codes: inf - inf = NaN
+                            float lo = d - delta;                        // padded codes: inf - inf = NaN
                             if (RANGED) {
                                 const bool ok = cb + c >= ls[b] && cb + c < le[b];
                                 up = ok ? up : __int_as_float(0x7F800000);
-                                lo[c] = ok ? lo[c] : __int_as_float(0x7FC00000);   // NaN: never a candidate
+                                lo = ok ? lo : __int_as_float(0x7FC00000);   // NaN: never a candidate
                             }
-                            sc[b].umin = fminf(sc[b].umin, up);
-                            lmin = fminf(lmin, lo[c]);                   // fminf drops the NaN
-                        }
-                        // only a lower bound below both the smallest upper bound so far and the worst kept one matters
-                        if (__any(lmin <= sc[b].umin && lmin < sc[b].kl[KEEP - 1])) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (lo[c] <= sc[b].umin) scan_insert(sc[b], lo[c], cb + c);   // NaN compares false
+                            sc[b].umin = fminf(sc[b].umin, up);          // the code's own, tighter bound
+                            if (lo <= sc[b].umin) scan_insert(sc[b], lo, cb + c);   // NaN compares false
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                sc[b].umin = fminf(sc[b].umin, __shfl_xor(sc[b].umin, 32));   // the two lane halves scan one token
+                if (h == 0 && tok[b] < N) atomicMin(tshare + tok[b], order_image(sc[b].umin));
             }
         }
     }
@@ -485,7 +581,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 struct FilterWorkspace {
-    int64_t xb, wb, se, xinv, winv, ubuf, lbuf, cbuf, cnt, cand, list, nlist, total;
+    int64_t xb, wb, se, xinv, winv, ubuf, lbuf, cbuf, cnt, cand, list, nlist, tshare, total;
     FilterWorkspace(int64_t N, int64_t K, int64_t D, int64_t scanners) {
         xb = 0;
         wb = align_up(xb + 2 * N * D, 256);
@@ -499,7 +595,8 @@ struct FilterWorkspace {
         cand = align_up(cnt + 4 * N, 256);
         list = align_up(cand + 4 * N * CAND_MAX, 256);
         nlist = align_up(list + 4 * N, 256);
-        total = align_up(nlist + 64, 256);
+        tshare = align_up(nlist + 64, 256);                 // int32 [N]: smallest upper bound any scanner has seen
+        total = align_up(tshare + 4 * N, 256);
     }
 };
 constexpr int MAX_SPLITS = 8;
@@ -563,6 +660,7 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     int* cand = reinterpret_cast<int*>(base + ws.cand);
     int* tok_list = reinterpret_cast<int*>(base + ws.list);
     int* n_list = reinterpret_cast<int*>(base + ws.nlist);
+    int* tshare = reinterpret_cast<int*>(base + ws.tshare);
     const int64_t kpad = t5vq_padded_codes(K);
 
     {
@@ -573,11 +671,11 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     if (compute_norms)                                                                                                 \
         hipLaunchKernelGGL((filter_prep_kernel<NCH_, true>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),    \
                            xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list);                                                                  \
+                           static_cast<int>(D), n_list, tshare);                                                               \
     else                                                                                                               \
         hipLaunchKernelGGL((filter_prep_kernel<NCH_, false>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),   \
                            xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list)
+                           static_cast<int>(D), n_list, tshare)
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }
@@ -611,7 +709,7 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
     reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv,                 \
         static_cast<int>(N), static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2),                    \
         static_cast<int>(splits), static_cast<int>(tiles_per_split), plain_map, c2, r, rg,                           \
-        static_cast<long long>(code_offset), ubuf, lbuf, cbuf
+        static_cast<long long>(code_offset), ubuf, lbuf, cbuf, tshare
     if (range)
         hipLaunchKernelGGL((filter_f16_kernel<true>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
     else
