@@ -333,7 +333,9 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                 }
                 if (kc == n_chunks - 1) {   // the bound other scanners of these tokens have published (any split, any CU)
 #pragma unroll
-                    for (int b = 0; b < TB; ++b) shared_u[b] = tshare[tok[b] < N ? tok[b] : N - 1];
+                    for (int b = 0; b < TB; ++b)   // device-scope load: a plain one may hit this CU's stale L1 line
+                        shared_u[b] = __hip_atomic_load(tshare + (tok[b] < N ? tok[b] : N - 1), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (kc == (n_chunks > 1 ? 1 : 0)) {
                     if (tid < CODE_TILE) {

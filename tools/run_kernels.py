@@ -19,7 +19,7 @@ from t5vqvae_amd import _lib  # noqa: E402
 _lib.load().t5vq_set_tuning(int(os.environ.get("T5VQ_TUNE", "0")))
 dev = torch.device("cuda", 0)
 n, k, d, update, _ = bench.WORKLOADS[workload]
-w, ema_w, cs, x = bench.build_state(workload, "uniform", 0, 1, dev)
+w, ema_w, cs, x = bench.build_state(workload, os.environ.get("T5VQ_REGIME", "uniform"), 0, 1, dev)
 if what == "dist":
     flat = x.reshape(-1, d)
     xx, ee = ops.row_sqnorms(flat, w)
