@@ -32,10 +32,13 @@ constexpr int KEEP = 4;                 // lowest lower bounds each scanner keep
                                         // wave of one code split: it sees a fixed subset of the codes of its token)
 constexpr int TOK_TILE = 256, CODE_TILE = 256, THREADS = 512;
 constexpr int BKC = 32;                 // 16-byte-aligned chunk of a row, in 4-byte units = 64 fp16
-constexpr int ROW = BKC + 4;            // LDS row stride (4-byte units): 144 B = 9 x 16 B, conflict-free b128 reads
+constexpr int ROW = BKC;                // unpadded 128-byte rows (an LDS-DMA instruction writes 1 KB contiguously); the
+                                        // 16-byte slot of piece p in row r is p ^ ((r >> 1) & 7): conflict-free b128 reads
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int X_IMG = TOK_TILE * ROW, W_IMG = CODE_TILE * ROW, STAGE = X_IMG + W_IMG;
 constexpr int EPI = 3 * CODE_TILE;         // per code of the tile: |e|^2, |e|, inverse row scale (epilogue operands)
-constexpr int LDS_BYTES = (2 * STAGE + 2 * EPI) * 4;   // 147,456 + 6,144 B: one workgroup (8 waves) per CU
+constexpr int LDS_BYTES = (2 * STAGE + 2 * EPI) * 4;   // 131,072 + 6,144 B: one workgroup (8 waves) per CU
 constexpr int F4_PER_ROW = BKC / 4, ROWS_PER_PASS = THREADS / F4_PER_ROW, XV = TOK_TILE / ROWS_PER_PASS,
               WV = CODE_TILE / ROWS_PER_PASS, G = BKC / 8;
 constexpr int TB = 2, CB = 4;           // 32x32 blocks per wave: 64 tokens x 128 codes
@@ -251,7 +254,12 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     const int total = n_tiles * n_chunks;
 
     if (n_tiles > 0) {
-        const int s_row = tid / F4_PER_ROW, s_col = (tid % F4_PER_ROW) * 4;
+        // LDS-DMA staging (global_load_lds_dwordx4): lane L of a wave-instruction fills the 16 bytes at base + 16 L =
+        // row (L / 8), slot (L % 8) of an 8-row slab; slot s of row r holds piece s ^ ((r >> 1) & 7) of the row's 8
+        // 16-byte pieces -- the swizzle sits on the SOURCE address, the LDS image stays lane-linear.  No VGPR round
+        // trip and no ds_write pass (the register form needed 32 staging VGPRs and spilled in the ranged kernel).
+        const int s_row = tid / F4_PER_ROW;                                   // row inside a 64-row pass
+        const int s_col = ((tid % F4_PER_ROW) ^ ((s_row >> 1) & 7)) * 4;      // source piece (4-byte units)
         const float* xrow[XV];
 #pragma unroll
         for (int j = 0; j < XV; ++j) {
@@ -259,53 +267,30 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
             if (t > N - 1) t = N - 1;
             xrow[j] = xb + static_cast<size_t>(t) * D2 + s_col;
         }
-        f32x4 sxv[XV], swv[WV];
-        auto load_stage = [&](int ct, int kc) {
+        auto issue_stage = [&](int buf, int ct, int kc) {
+            float* xs = lds + buf * STAGE + wave * 8 * ROW;
+            float* ws = xs + X_IMG;
 #pragma unroll
-            for (int j = 0; j < XV; ++j) sxv[j] = *reinterpret_cast<const f32x4*>(xrow[j] + kc * BKC);
+            for (int j = 0; j < XV; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xrow[j] + kc * BKC),
+                                                 (lds_ptr_t)(xs + ROWS_PER_PASS * j * ROW), 16, 0, 0);
 #pragma unroll
             for (int j = 0; j < WV; ++j) {
                 int c = (tile_begin + ct) * CODE_TILE + s_row + ROWS_PER_PASS * j;
                 if (c > K - 1) c = K - 1;
-                swv[j] = *reinterpret_cast<const f32x4*>(wb + static_cast<size_t>(c) * D2 + s_col + kc * BKC);
+                __builtin_amdgcn_global_load_lds(
+                    (gbl_ptr_t)(wb + static_cast<size_t>(c) * D2 + s_col + kc * BKC),
+                    (lds_ptr_t)(ws + ROWS_PER_PASS * j * ROW), 16, 0, 0);
             }
         };
-        auto store_stage = [&](int buf) {
-            float* xs = lds + buf * STAGE;
-            float* ws = xs + X_IMG;
-#pragma unroll
-            for (int j = 0; j < XV; ++j)
-                *reinterpret_cast<f32x4*>(xs + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = sxv[j];
-#pragma unroll
-            for (int j = 0; j < WV; ++j)
-                *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
-        };
-        // one quarter of a stage: written to LDS and re-issued behind the MFMAs of one 16-deep step
-        static_assert(XV == G && WV == G, "one x and one w register set per 16-deep step");
-        auto restage_part = [&](int j, int buf, int ct, int kc) {
-            float* xs = lds + buf * STAGE;
-            float* ws = xs + X_IMG;
-#ifndef T5VQ_AB_NOWRITE
-            *reinterpret_cast<f32x4*>(xs + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = sxv[j];
-            *reinterpret_cast<f32x4*>(ws + (s_row + ROWS_PER_PASS * j) * ROW + s_col) = swv[j];
-#endif
-#ifndef T5VQ_AB_NOLOAD
-            sxv[j] = *reinterpret_cast<const f32x4*>(xrow[j] + kc * BKC);
-            int c = (tile_begin + ct) * CODE_TILE + s_row + ROWS_PER_PASS * j;
-            if (c > K - 1) c = K - 1;
-            swv[j] = *reinterpret_cast<const f32x4*>(wb + static_cast<size_t>(c) * D2 + s_col + kc * BKC);
-#endif
-        };
-
-        // Staging pipeline: ONE register set; the tile for step it+1 is written to LDS right AFTER the barrier that
-        // ends step it-1 (its buffer is free from then on) and the loads for step it+2 are re-issued at once, so
-        // every load has a whole step of MFMAs to land.
-        load_stage(0, 0);
-        store_stage(0);
-        int lct = 0, lkc = 1;                       // (code tile, chunk) of the next stage to load
-        if (lkc == n_chunks) { lkc = 0; lct = 1; }
-        if (total > 1) load_stage(lct, lkc);        // registers now hold step 1
+        // Two buffers: stage it+1 is issued at the top of step it (its buffer is free since the barrier that ended
+        // step it-1) and has to land by the wait + barrier that end step it -- the DMA's data is ordered for a
+        // ds_read only by the issuing wave's vmcnt wait followed by a barrier the reader has passed.
+        issue_stage(0, 0, 0);
+        int lct = 0, lkc = 0;                       // (code tile, chunk) of the stage issued last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const int rd_sw = (l31 >> 1) & 7;           // the reader's rows are 32 k + l31: (row >> 1) & 7 is the lane's
         int it = 0;
         for (int ct = 0; ct < n_tiles; ++ct) {
             f32x16 acc[TB][CB];
@@ -345,28 +330,29 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                         epi[2 * CODE_TILE + (tid & (CODE_TILE - 1))] = ep0;
                     }
                 }
-                const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW + 4 * h;
-                const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW + 4 * h;
-                // step it+1 (loaded during step it-1) is written and step it+2 fetched in four parts, one behind each
-                // 16-deep step's MFMAs, without branches: past the end the last stage is fetched again and the
-                // write lands in a buffer nobody reads any more
-                if (it + 2 < total && ++lkc == n_chunks) { lkc = 0; ++lct; }
+                const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW;
+                const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW;
+                // stage it+1 goes straight into the other buffer (free since the barrier that ended step it-1) and
+                // must have landed by this step's closing barrier; past the end the last stage is fetched again
+                if (it + 1 < total && ++lkc == n_chunks) { lkc = 0; ++lct; }
+                issue_stage((it + 1) & 1, lct, lkc);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    restage_part(g, (it + 1) & 1, lct, lkc);
                     f16x8 bf[TB], af[CB];
+                    const int piece = ((2 * g + h) ^ rd_sw) * 4;
 #pragma unroll
                     for (int b = 0; b < TB; ++b)
-                        bf[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(xs + b * 32 * ROW + 8 * g));
+                        bf[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(xs + b * 32 * ROW + piece));
 #pragma unroll
                     for (int t = 0; t < CB; ++t)
-                        af[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + 8 * g));
+                        af[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(ws + t * 32 * ROW + piece));
 #pragma unroll
                     for (int t = 0; t < CB; ++t)
 #pragma unroll
                         for (int b = 0; b < TB; ++b)
                             acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[b], acc[b][t], 0, 0, 0);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
             // epilogue: d~ = fl(fl(xx + ee) - 2 dot~), delta = c2 |x| |e| + r (xx + ee); U = d~ + delta, L = d~ - delta.

@@ -3,7 +3,7 @@
     python3 tools/experiments/filter_variant.py path/to/libt5vq_variant.so [more.so ...]
 One process per library (the binding loads one library per process): the parent starts itself once per path.
 Diagnostic builds of t5vq_filter.hip: -DT5VQ_AB_NOEPI (no epilogue), -DT5VQ_AB_NOSLOW (no per-element path in the
-epilogue), -DT5VQ_AB_NOLOAD / -DT5VQ_AB_NOWRITE (no global loads / LDS writes in the k loop); their results are wrong
+epilogue); their results are wrong
 by construction, only tools/experiments/ab_prof.sh's kernel time means anything.
 """
 import os
