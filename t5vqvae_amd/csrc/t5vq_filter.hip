@@ -462,48 +462,77 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 
 // ---- collect: T_i = min over scanners of umin; candidates = kept pairs with lower bound <= T_i.  A scanner whose
 // KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
+// L lanes per token, one per scanner (L = 4, 8, 16, 32 >= n_scanners): with one thread per token a small batch with
+// many code splits walked 32 x 9 dependent loads in 12 workgroups (C1: 76 us).  Candidates keep the (scanner, slot)
+// order through a prefix sum over the token's lanes.
+template <int L>
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
                                                       long long code_offset, int* __restrict__ cnt,
                                                       int* __restrict__ cand, long long* __restrict__ keys,
                                                       int* __restrict__ tok_list, int* __restrict__ n_list) {
-    const int tok = blockIdx.x * 256 + threadIdx.x;
-    if (tok >= N) return;
+    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    const int tok = static_cast<int>(gid / L), s = static_cast<int>(gid % L);
+    if (tok >= N) return;   // a token's L lanes leave together: the shuffles below stay inside live groups
     if (range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
         const long long a = range[2 * static_cast<size_t>(tok)] - code_offset;
         const long long e = range[2 * static_cast<size_t>(tok) + 1] - code_offset;
         if ((e < K ? e : K) <= (a > 0 ? a : 0)) {
-            keys[tok] = KEY_NONE;
-            cnt[tok] = 0;
+            if (s == 0) {
+                keys[tok] = KEY_NONE;
+                cnt[tok] = 0;
+            }
             return;
         }
     }
-    float T = __int_as_float(0x7F800000);
-    for (int s = 0; s < n_scanners; ++s) T = fminf(T, ubuf[static_cast<size_t>(s) * N + tok]);
-    int n = 0, first = -1;
-    bool overflow = false;
-    for (int s = 0; s < n_scanners; ++s) {
-        int q = 0;
+    const bool live = s < n_scanners;
+    float T = live ? ubuf[static_cast<size_t>(s) * N + tok] : __int_as_float(0x7F800000);
 #pragma unroll
-        for (int i = 0; i < KEEP; ++i) {
-            const float l = lbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
-            const int c = cbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
-            if (c >= 0 && l <= T) {
-                ++q;
-                if (n == 0) first = c;
-                if (n < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + n] = c;
-                ++n;
-            }
+    for (int o = L / 2; o > 0; o >>= 1) T = fminf(T, __shfl_xor(T, o));
+    int c[KEEP];
+    bool ok[KEEP];
+    int q = 0, first = -1;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        float l = 0.f;
+        c[i] = -1;
+        if (live) {
+            l = lbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
+            c[i] = cbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
         }
-        overflow |= q == KEEP;
+        ok[i] = c[i] >= 0 && l <= T;
+        if (ok[i] && first < 0) first = c[i];
+        q += ok[i] ? 1 : 0;
     }
+    int incl = q;   // inclusive prefix over the token's lanes
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) {
+        const int v = __shfl_up(incl, o, L);
+        if (s >= o) incl += v;
+    }
+    const int n = __shfl(incl, L - 1, L);
+    int overflow = q == KEEP ? 1 : 0;
+    int f = (q > 0 && incl == q) ? first : -1;   // the first qualifying pair of the first scanner that has one
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+        overflow |= __shfl_xor(overflow, o);
+        f = max(f, __shfl_xor(f, o));
+    }
+    int slot = incl - q;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i)
+        if (ok[i]) {
+            if (slot < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + slot] = c[i];
+            ++slot;
+        }
+    if (s != 0) return;
     if (overflow || n > CAND_MAX || n == 0) {   // n == 0: NaN / inf rows -- whatever the scan does with them
         keys[tok] = KEY_NONE;                   // the listed scan merges into it with atomicMin
         tok_list[atomicAdd(n_list, 1)] = tok;
         cnt[tok] = 0;
     } else if (n == 1 && !exact_keys) {         // the index is decided; T_i (an upper bound of its distance) fills
-        const long long gi = code_offset + first - (range ? range[2 * static_cast<size_t>(tok)] : 0);
+        const long long gi = code_offset + f - (range ? range[2 * static_cast<size_t>(tok)] : 0);
         keys[tok] = pack_key(T, static_cast<int>(gi));   // the key's distance word (index: slice-relative if ranged)
         cnt[tok] = 0;
     } else {
@@ -704,10 +733,17 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
         hipLaunchKernelGGL((filter_f16_kernel<false>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
 #undef T5VQ_FILTER_ARGS
     T5VQ_I_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(collect_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, stream, ubuf, lbuf,
-                       cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners), exact_keys, rg,
-                       static_cast<long long>(code_offset), cnt, cand, reinterpret_cast<long long*>(keys), tok_list,
-                       n_list);
+#define T5VQ_COLLECT(L_)                                                                                          \
+    hipLaunchKernelGGL((collect_kernel<L_>), dim3(static_cast<unsigned>((N * L_ + 255) / 256)), dim3(256), 0, stream,  \
+                       ubuf, lbuf, cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners),      \
+                       exact_keys, rg, static_cast<long long>(code_offset), cnt, cand,                               \
+                       reinterpret_cast<long long*>(keys), tok_list, n_list)
+    static_assert(4 * MAX_SPLITS <= 32, "collect_kernel: one lane per scanner, at most 32 lanes per token");
+    if (scanners <= 4) { T5VQ_COLLECT(4); }
+    else if (scanners <= 8) { T5VQ_COLLECT(8); }
+    else if (scanners <= 16) { T5VQ_COLLECT(16); }
+    else { T5VQ_COLLECT(32); }
+#undef T5VQ_COLLECT
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
                        xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), rg,
