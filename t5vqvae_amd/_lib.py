@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libt5vq.so")
+# T5VQ_LIB: another build of the same library (variant builds for A/B timing); there is still no CPU path behind it
+LIB_PATH = os.environ.get("T5VQ_LIB") or os.path.join(_HERE, "csrc", "libt5vq.so")
 
 P = c_void_p
 I64 = c_int64

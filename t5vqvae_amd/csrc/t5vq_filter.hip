@@ -464,8 +464,8 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 // KEEP kept pairs all qualify may have dropped further ones: the token is then decided by the exact scan.
 // L lanes per token, one per scanner (L = 4, 8, 16, 32 >= n_scanners): with one thread per token a small batch with
 // many code splits walked 32 x 9 dependent loads in 12 workgroups (C1: 76 us).  Candidates keep the (scanner, slot)
-// order through a prefix sum over the token's lanes.
-template <int L>
+// order through a prefix sum over the token's lanes (any order would do: refine takes the packed-key minimum).
+template <int L, int R>   // R scanners per lane (2 only with L = 64: up to 128 scanners)
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
@@ -486,24 +486,34 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
             return;
         }
     }
-    const bool live = s < n_scanners;
-    float T = live ? ubuf[static_cast<size_t>(s) * N + tok] : __int_as_float(0x7F800000);
+    float T = __int_as_float(0x7F800000);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (s + r * L < n_scanners) T = fminf(T, ubuf[static_cast<size_t>(s + r * L) * N + tok]);
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) T = fminf(T, __shfl_xor(T, o));
-    int c[KEEP];
-    bool ok[KEEP];
-    int q = 0, first = -1;
+    int c[R * KEEP];
+    bool ok[R * KEEP];
+    int q = 0, first = -1, overflow = 0;
 #pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-        float l = 0.f;
-        c[i] = -1;
-        if (live) {
-            l = lbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
-            c[i] = cbuf[(static_cast<size_t>(s) * KEEP + i) * N + tok];
+    for (int r = 0; r < R; ++r) {
+        const int sc = s + r * L;
+        int qs = 0;
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            float l = 0.f;
+            int ci = -1;
+            if (sc < n_scanners) {
+                l = lbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
+                ci = cbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
+            }
+            c[r * KEEP + i] = ci;
+            ok[r * KEEP + i] = ci >= 0 && l <= T;
+            if (ok[r * KEEP + i] && first < 0) first = ci;
+            qs += ok[r * KEEP + i] ? 1 : 0;
         }
-        ok[i] = c[i] >= 0 && l <= T;
-        if (ok[i] && first < 0) first = c[i];
-        q += ok[i] ? 1 : 0;
+        overflow |= qs == KEEP ? 1 : 0;
+        q += qs;
     }
     int incl = q;   // inclusive prefix over the token's lanes
 #pragma unroll
@@ -512,8 +522,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         if (s >= o) incl += v;
     }
     const int n = __shfl(incl, L - 1, L);
-    int overflow = q == KEEP ? 1 : 0;
-    int f = (q > 0 && incl == q) ? first : -1;   // the first qualifying pair of the first scanner that has one
+    int f = (q > 0 && incl == q) ? first : -1;   // the first qualifying pair of the first lane that has one
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) {
         overflow |= __shfl_xor(overflow, o);
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
     }
     int slot = incl - q;
 #pragma unroll
-    for (int i = 0; i < KEEP; ++i)
+    for (int i = 0; i < R * KEEP; ++i)
         if (ok[i]) {
             if (slot < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + slot] = c[i];
             ++slot;
@@ -616,17 +625,21 @@ struct FilterWorkspace {
         total = align_up(tshare + 4 * N, 256);
     }
 };
-constexpr int MAX_SPLITS = 8;
+constexpr int MAX_SPLITS = 32;   // 4 scanners each: collect_kernel handles up to 128
+constexpr int MIN_TILES = 1;
 
-// code splits: fill the 256 workgroup slots, at most MAX_SPLITS, at least 4 code tiles each (more, shorter splits
-// were measured slower at C1: 20 splits of 2 tiles 289 us vs 8 splits of 5 tiles 253 us -- per-workgroup set-up and
-// the scanner records grow with the split count)
+// code splits: the fewest code tiles per workgroup for which all workgroups still run at once (<= 256), at most
+// MAX_SPLITS.  C1 (12 token tiles, 40 code tiles): 20 splits of 2 tiles, search 113 us; 8 splits of 5 tiles 165 us.
+// (An earlier measurement had more splits slower: that was the one-thread-per-token collect kernel, not the splits.)
 int64_t plan_filter_splits(int64_t N, int64_t K) {
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
-    int64_t splits = 1;
-    while (splits < MAX_SPLITS && tok_tiles * splits < 256 && code_tiles / (splits * 2) >= 2) splits *= 2;
-    return splits;
+    // the fewest code tiles per workgroup (at least MIN_TILES) for which all workgroups still run at once
+    for (int64_t t = MIN_TILES; t < code_tiles; ++t) {
+        const int64_t splits = (code_tiles + t - 1) / t;
+        if (splits <= MAX_SPLITS && tok_tiles * splits <= 256) return splits;
+    }
+    return 1;
 }
 bool attr_done[64] = {};
 
@@ -733,16 +746,18 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
         hipLaunchKernelGGL((filter_f16_kernel<false>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
 #undef T5VQ_FILTER_ARGS
     T5VQ_I_CHECK_HIP(hipGetLastError());
-#define T5VQ_COLLECT(L_)                                                                                          \
-    hipLaunchKernelGGL((collect_kernel<L_>), dim3(static_cast<unsigned>((N * L_ + 255) / 256)), dim3(256), 0, stream,  \
+#define T5VQ_COLLECT(L_, R_)                                                                                      \
+    hipLaunchKernelGGL((collect_kernel<L_, R_>), dim3(static_cast<unsigned>((N * L_ + 255) / 256)), dim3(256), 0, stream,  \
                        ubuf, lbuf, cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners),      \
                        exact_keys, rg, static_cast<long long>(code_offset), cnt, cand,                               \
                        reinterpret_cast<long long*>(keys), tok_list, n_list)
-    static_assert(4 * MAX_SPLITS <= 32, "collect_kernel: one lane per scanner, at most 32 lanes per token");
-    if (scanners <= 4) { T5VQ_COLLECT(4); }
-    else if (scanners <= 8) { T5VQ_COLLECT(8); }
-    else if (scanners <= 16) { T5VQ_COLLECT(16); }
-    else { T5VQ_COLLECT(32); }
+    static_assert(4 * MAX_SPLITS <= 128, "collect_kernel: at most 64 lanes per token, two scanners each");
+    if (scanners <= 4) { T5VQ_COLLECT(4, 1); }
+    else if (scanners <= 8) { T5VQ_COLLECT(8, 1); }
+    else if (scanners <= 16) { T5VQ_COLLECT(16, 1); }
+    else if (scanners <= 32) { T5VQ_COLLECT(32, 1); }
+    else if (scanners <= 64) { T5VQ_COLLECT(64, 1); }
+    else { T5VQ_COLLECT(64, 2); }
 #undef T5VQ_COLLECT
     T5VQ_I_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
