@@ -261,6 +261,16 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
                         t5vq_stream_t stream);
 
+/* The same forward (vqvae/vqvae.py:103-128,147-152,160 + :133,:141) with the filtered search of
+ * t5vq_dist_argmin_filtered_f32 in place of the scan: identical indices and outputs, one host call.  Needs
+ * D % 64 == 0, 64 <= D <= 4096.  workspace: t5vq_forward_filtered_workspace_bytes(N, K, D) bytes, 256-byte aligned.
+ * n_overflow (nullable, device int32[1]): tokens the filter could not settle (decided by the scan kernel). */
+int64_t t5vq_forward_filtered_workspace_bytes(int64_t N, int64_t K, int64_t D);
+int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
+                                 int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                                 float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                                 int32_t* n_overflow, t5vq_stream_t stream);
+
 /* t5vq_vq_ema_finalize_f32 = vqvae/vqvae.py:131-144 (if update != 0) and the loss / perplexity scalars
  * (:148/:152,:157,:161-162): t5vq_ema_cluster_f32 (mode 1 or 0) followed by t5vq_ema_embed_f32.  A
  * token-sharded caller all-reduces counts / embed_sum / loss_sum between the two composite calls. */

@@ -2225,6 +2225,48 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
     return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
 }
 
+// The same forward with the filtered search (t5vq_filter.hip) in place of the scan: [fp16 images + row norms] ->
+// [fp16 filter] -> [collect] -> [refine] -> [scan of the unsettled tokens] -> ([order tokens by code]) ->
+// [gather + statistics] -> [loss sum].  Workspace = the scan form's, then the filter's.
+int64_t t5vq_forward_filtered_workspace_bytes(int64_t N, int64_t K, int64_t D) {
+    if (N < 0 || K < 0 || D < 0) return 0;
+    return FwdWorkspace(N, K).total + t5vq_filter_workspace_bytes(N, K, D);
+}
+
+int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
+                                 int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                                 float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                                 int32_t* n_overflow, t5vq_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    const FwdWorkspace ws(N, K);
+    const int64_t filter_bytes = t5vq_filter_workspace_bytes(N, K, D);
+    T5VQ_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace null or not 256-byte aligned");
+    T5VQ_REQUIRE(workspace_bytes >= ws.total + filter_bytes,
+                 "workspace smaller than t5vq_forward_filtered_workspace_bytes(N, K, D)");
+    T5VQ_REQUIRE(x && w, "null input");
+    char* base = static_cast<char*>(workspace);
+    int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
+    float* xx = reinterpret_cast<float*>(base + ws.xx);
+    float* ee = reinterpret_cast<float*>(base + ws.ee);
+    float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
+    // index-only keys: the distance word of a token with a single candidate is an upper bound, not the distance
+    int rc = t5vq_dist_argmin_filtered_f32(x, w, xx, ee, 1, range, N, K, D, 0, 0, base + ws.total, filter_bytes, keys,
+                                           n_overflow, stream_);
+    if (rc != T5VQ_OK) return rc;
+    const int32_t* perm = nullptr;
+    if (embed_sum && N >= GS_SMALL_N) {
+        int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
+        rc = t5vq_order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        if (rc != T5VQ_OK) return rc;
+        perm = p;
+    }
+    rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
+                       partial, false, perm, stream);
+    if (rc != T5VQ_OK || !loss_sum) return rc;
+    return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
+}
+
 int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
                              const float* embed_sum, const float* loss_sum, int64_t K, int64_t D, int64_t n_tokens,
                              float loss_denom, float decay, float one_minus_decay, float epsilon, float k_epsilon,

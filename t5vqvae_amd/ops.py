@@ -262,6 +262,42 @@ def vq_forward(x, w, ranges, loss: str, *, xx=None, ste=None, q=None, diff=None,
                                            _p(loss_sum), _stream(x)), "vq_forward")
 
 
+def vq_forward_filtered(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None, counts=None,
+                        embed_sum=None, loss_sum=None):
+    """vq_forward with the filtered search (t5vq_vq_forward_filtered_f32): same outputs, one host call.  Returns the
+    device int32[1] count of tokens the filter left to the scan kernel."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d:
+        raise RuntimeError("vq_forward_filtered: x and w disagree on D")
+    if d % 64 or d > 4096:
+        raise RuntimeError("the filtered search needs D % 64 == 0, D <= 4096")
+    if ranges is not None:
+        _need(ranges, "ranges", torch.int64, 2)
+        if tuple(ranges.shape) != (n, 2):
+            raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
+    for name, t, numel in (("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
+                           ("embed_sum", embed_sum, k * d), ("loss_sum", loss_sum, 1)):
+        if t is not None:
+            _need(t, name)
+            if t.numel() != numel:
+                raise RuntimeError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
+    if idx is not None:
+        _need(idx, "idx", torch.int64)
+        if idx.numel() != n:
+            raise RuntimeError(f"idx: expected {n} elements")
+    nbytes = int(lib.t5vq_forward_filtered_workspace_bytes(n, k, d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    ovf = torch.empty(1, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_vq_forward_filtered_f32(_p(x), _p(w), _p(ranges), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
+                                                    _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
+                                                    _p(loss_sum), _p(ovf), _stream(x)), "vq_forward_filtered")
+    return ovf
+
+
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: int, loss_denom: float, decay: float,
                  one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float,
                  plain_variant: bool, update: bool, scalars):

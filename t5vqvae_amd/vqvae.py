@@ -185,6 +185,11 @@ class _QuantizerBase(nn.Module):
     def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0):
         keys, ovf = ops.dist_argmin_filtered(x, w, want_overflow=True, exact_keys=exact_keys, ranges=ranges,
                                              code_offset=code_offset)
+        self._note_unsettled(ovf, x.shape[0])
+        return keys
+
+    def _note_unsettled(self, ovf, n_tokens):
+        """Remember the filter's unsettled-token count (device) and, in "auto", start its asynchronous read-back."""
         if self.search == "auto" and not torch.cuda.is_current_stream_capturing():
             st = _filter_state(self)
             if st["pending"] is None:                  # asynchronous read-back of the unsettled-token count
@@ -192,9 +197,8 @@ class _QuantizerBase(nn.Module):
                 host.copy_(ovf, non_blocking=True)
                 event = torch.cuda.Event()
                 event.record()
-                st["pending"] = (event, host, x.shape[0])
+                st["pending"] = (event, host, n_tokens)
         self.last_unsettled = ovf
-        return keys
 
     def _absolute(self, keys, ranges):
         """index_mode "absolute": slice-relative index + start (the index is the key's low word; rows whose range
@@ -224,8 +228,13 @@ class _QuantizerBase(nn.Module):
         diff = torch.empty_like(x) if want_diff else None
         q = torch.empty_like(x) if want_q else None
         use_filter = self._use_filter(x, w, ranges)
-        if (ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute")) or use_filter:
-            # role-bucketed search (permute, search, scatter back) or filtered search, then the fine-grained calls
+        bucketed = ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute")
+        if use_filter and not bucketed:                          # the filtered forward behind one host call
+            ovf = ops.vq_forward_filtered(x, w, ranges, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
+                                          embed_sum=embed_sum, loss_sum=loss_sum)
+            self._note_unsettled(ovf, n)
+        elif bucketed:
+            # role-bucketed search (permute, search, scatter back; scan or filter), then the fine-grained calls
             keys = self._absolute(self._nearest_keys(x, w, ranges, xx=plan.xx, exact_keys=False,
                                                      use_filter=use_filter), ranges)
             # embed_sum wanted and enough tokens: walk them grouped by code (one flush per run of equal codes)

@@ -137,6 +137,13 @@ def vq_forward(x, w, ranges, loss, *, xx=None, ste=None, q=None, diff=None, idx=
         reduce_partials(partial, loss_sum)
 
 
+def vq_forward_filtered(x, w, ranges, loss, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
+                        loss_sum=None):
+    vq_forward(x, w, ranges, loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts, embed_sum=embed_sum,
+               loss_sum=loss_sum)
+    return torch.zeros(1, dtype=torch.int32)
+
+
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens, loss_denom, decay, one_minus_decay,
                  epsilon, k_epsilon, commitment_cost, plain_variant, update, scalars):
     ema_cluster(cluster_size if update else None, counts, loss_sum, counts.numel(), n_tokens, loss_denom, decay,

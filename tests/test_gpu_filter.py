@@ -224,3 +224,29 @@ def test_filter_survives_worst_case_aligned_rounding():
     for scale_x, scale_w in ((1e-3, 1e3), (37.0, 1.0 / 37.0)):   # row scalings must not matter
         scan, filt, _ = both((x * scale_x).contiguous(), (w * scale_w).contiguous())
         assert torch.equal(scan, filt)
+
+
+@pytest.mark.parametrize("n,k,d,ranged,loss", [(2880, 10000, 768, False, "mse"), (40000, 1000, 768, False, "mse"),
+                                               (900, 640, 128, True, "cosine")])
+def test_composite_filtered_forward_equals_the_scan_form(n, k, d, ranged, loss):
+    """t5vq_vq_forward_filtered_f32 (one host call) == t5vq_vq_forward_f32: every per-token output, the counts and
+    the loss sum bit for bit; embed_sum up to the order of its atomics."""
+    from t5vqvae_amd import ops, synth
+    dev = "cuda"
+    w = synth.normal((k, d), 61, 0, device=dev)
+    x, _ = synth.clustered(n, w, 0.7, 62)
+    x = x.to(dev)
+    rg = synth.role_ranges(n, [(0, k // 3), (k // 3, k)], 63, 0, device=dev) if ranged else None
+
+    def bufs():
+        return dict(ste=torch.empty_like(x), q=torch.empty_like(x), diff=torch.empty_like(x),
+                    idx=torch.empty(n, dtype=torch.int64, device=dev), counts=torch.empty(k, device=dev),
+                    embed_sum=torch.empty(k, d, device=dev), loss_sum=torch.empty(1, device=dev))
+    a, b = bufs(), bufs()
+    ops.vq_forward(x, w, rg, loss, **a)
+    ovf = ops.vq_forward_filtered(x, w, rg, loss, **b)
+    assert int(ovf) >= 0
+    for name in ("ste", "q", "diff", "idx", "counts", "loss_sum"):
+        assert torch.equal(a[name], b[name]), name
+    den = float(a["embed_sum"].double().norm())
+    assert float((a["embed_sum"].double() - b["embed_sum"].double()).norm()) <= 1e-6 * den
