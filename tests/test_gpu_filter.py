@@ -250,3 +250,41 @@ def test_composite_filtered_forward_equals_the_scan_form(n, k, d, ranged, loss):
         assert torch.equal(a[name], b[name]), name
     den = float(a["embed_sum"].double().norm())
     assert float((a["embed_sum"].double() - b["embed_sum"].double()).norm()) <= 1e-6 * den
+
+
+def test_filtered_keys_identical_to_scan_on_random_shapes():
+    """Shape fuzz (fixed seed): ragged token / code counts around the 256 x 256 tile and the split planner's
+    boundaries, every supported row length class, plain and role-ranged, three data regimes; run twice (the second
+    pass reuses whatever the first left in the caches and in the workspace allocator).  Full keys must equal the
+    scan's every time."""
+    import random
+    from t5vqvae_amd import ops
+    rnd = random.Random(20240511)
+    dims = [64, 128, 192, 256, 512, 768, 1024]
+    cases = []
+    for _ in range(96):
+        n = rnd.choice([1, 63, 255, 256, 257, 511, 777, 2880, 3001, 5000, 9000])
+        k = rnd.choice([1, 31, 255, 256, 257, 513, 1000, 2049, 5000, 10000])
+        cases.append((n, k, rnd.choice(dims), rnd.random() < 0.4, rnd.randrange(3)))
+    bad = []
+    for rep in range(2):
+        for i, (n, k, d, ranged, regime) in enumerate(cases):
+            w = synth.normal((k, d), 500 + i, 0, device="cuda")
+            if regime == 0:
+                x = synth.normal((n, d), 600 + i, 0, device="cuda")
+            elif regime == 1:
+                x = synth.clustered(n, w, 0.3, 600 + i)[0].cuda()
+            else:                                           # near-ties: every token sits between two codewords
+                a = synth.uniform_int(n, k, 700 + i, 0, "cuda")
+                b = synth.uniform_int(n, k, 700 + i, 1, "cuda")
+                x = 0.5 * (w[a] + w[b]) + 1e-4 * synth.normal((n, d), 600 + i, 0, device="cuda")
+            rg = None
+            if ranged:
+                cut = max(1, k // 3)
+                rg = synth.role_ranges(n, [(0, cut), (cut, k), (0, k), (cut, cut)], 800 + i, 0, device="cuda")
+            xx, ee = ops.row_sqnorms(x, w)
+            scan = ops.dist_argmin(x, w, xx, ee, rg)
+            filt = ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg)
+            if not torch.equal(scan, filt):
+                bad.append((rep, n, k, d, ranged, regime, int((scan != filt).sum())))
+    assert not bad, bad
