@@ -200,8 +200,9 @@ struct Frag {
 
 // BOUNDED (top-k passes): `range` is reinterpreted as one packed key per token and only (distance, code) pairs that
 // order strictly AFTER that key are admissible -- pass j of a top-k search excludes the j best found so far.
-// LISTED (decision scan of the filtered search): only the tokens named in tok_list[0 .. *n_listed) are searched;
-// the grid is sized for N tokens and workgroups beyond the list return at once.
+// LISTED (decision scan of the filtered search): only the tokens named in tok_list[0 .. *n_listed) are searched.  The
+// host does not know the list's length: the grid is a fixed few workgroups per CU that stride over the (token tile,
+// split) pairs the list needs (a grid sized for all N tokens spent 13 us dispatching workgroups that return at once).
 template <class C, bool RANGED, bool WRITE_DIST, bool BOUNDED = false, bool LISTED = false>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
@@ -224,16 +225,25 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
 
     // Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness): the n_splits
     // workgroups of one token tile are given ids 8 apart so that their X tile is fetched into ONE L2.
-    const int grp = blockIdx.x / (8 * n_splits);
-    const int split = (blockIdx.x / 8) % n_splits;
-    const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
-    if (tok_base >= N) return;
+    // One pass for a grid that covers every (token tile, split); LISTED: virtual block ids vb, vb + gridDim, ...
+    // (`continue` in a do-while jumps to its condition: the early exits below end the pass, not the workgroup)
+    unsigned vb = blockIdx.x;
+    const unsigned vb_total =
+        LISTED ? static_cast<unsigned>((N + 8 * TOK_TILE - 1) / (8 * TOK_TILE)) * 8u * static_cast<unsigned>(n_splits) : 0u;
+    bool again = false;
+    do {
+    if (again) __syncthreads();   // the previous pass's LDS reads are done before this pass restages
+    again = true;
+    const int grp = vb / (8 * n_splits);
+    const int split = (vb / 8) % n_splits;
+    const int tok_base = (grp * 8 + (vb & 7)) * TOK_TILE;
+    if (tok_base >= N) continue;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     const int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
     const int n_tiles = tile_end - tile_begin;
-    if (n_tiles <= 0) return;
+    if (n_tiles <= 0) continue;
     const int n_chunks = (D + BKC - 1) / BKC;
     const int total = n_tiles * n_chunks;
 
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
         }
     }
 
-    if (WRITE_DIST) return;
+    if (WRITE_DIST) continue;
 
     // merge the two lane halves (codes 4h + ...), lowest index wins ties
     const float ob = __shfl_xor(best, 32);
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
             keys[tok_c] = key;
         }
     }
+    } while (LISTED && (vb += gridDim.x) < vb_total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1648,7 +1659,9 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
                            reinterpret_cast<long long*>(keys), static_cast<long long>(N));
         T5VQ_CHECK_HIP(hipGetLastError());
     }
-    const dim3 grid(static_cast<unsigned>((tok_tiles + 7) / 8 * 8 * splits));
+    int64_t n_blocks = (tok_tiles + 7) / 8 * 8 * splits;
+    if (opts.tok_list && n_blocks > 2048) n_blocks = 2048;   // listed tokens: the workgroups stride over what the list needs
+    const dim3 grid(static_cast<unsigned>(n_blocks));
     const long long* rg = reinterpret_cast<const long long*>(range);
     long long* kp = reinterpret_cast<long long*>(keys);
 #define T5VQ_DIST_ARGS                                                                                        \
