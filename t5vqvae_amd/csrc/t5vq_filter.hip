@@ -62,8 +62,32 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           _Float16* __restrict__ wh, float* __restrict__ w_inv,
                                                           float* __restrict__ xx, float* __restrict__ ee,
                                                           long long kpad, float* __restrict__ se, int D,
-                                                          int* __restrict__ n_list, int* __restrict__ tshare) {
+                                                          int* __restrict__ n_list, int* __restrict__ tshare,
+                                                          unsigned row_blocks, T5vqZeroArgs zero) {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x >= row_blocks) {   // the tail of the grid zeroes the caller's buffers: 4096 words per workgroup
+        long long i = (static_cast<long long>(blockIdx.x - row_blocks) * 256 + threadIdx.x) * 16;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (i < zero.n[r]) {
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) {
+                    float* dst = static_cast<float*>(zero.p[r]) + i + j;
+                    if (i + j + 4 <= zero.n[r]) {
+                        *reinterpret_cast<f32x4*>(dst) = z;
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (i + j + e < zero.n[r]) dst[e] = 0.f;
+                    }
+                }
+                return;
+            }
+            i -= (zero.n[r] + 4095) / 4096 * 4096;
+            if (i < 0) return;
+        }
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_list = 0;
     long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const float* src;
@@ -656,7 +680,16 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
                                   const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
                                   int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    T5vqZeroArgs zero = {};
+    return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, N, K, D, code_offset, exact_keys,
+                                              workspace, workspace_bytes, keys, n_overflow, zero,
+                                              static_cast<hipStream_t>(stream_));
+}
+
+int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
+                                       const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
+                                       int exact_keys, void* workspace, int64_t workspace_bytes, int64_t* keys,
+                                       int32_t* n_overflow, T5vqZeroArgs zero, hipStream_t stream) {
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
     T5VQ_I_REQUIRE(D >= 64 && D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, 64 <= D <= 4096");
@@ -695,17 +728,25 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
 
     {
         const int64_t rows = N + kpad;   // x rows, then w rows and the |e|^2 padding
-        const dim3 pgrid(static_cast<unsigned>((rows + 3) / 4));
+        const unsigned row_blocks = static_cast<unsigned>((rows + 3) / 4);
+        long long zero_blocks = 0;
+        for (int r = 0; r < 3; ++r) {
+            T5VQ_I_REQUIRE(zero.n[r] >= 0 && (zero.n[r] == 0 || zero.p[r]) &&
+                               (reinterpret_cast<uintptr_t>(zero.p[r]) & 15u) == 0,
+                           "zero regions must be 16-byte aligned");
+            zero_blocks += (zero.n[r] + 4095) / 4096;
+        }
+        const dim3 pgrid(row_blocks + static_cast<unsigned>(zero_blocks));
         const int nch = static_cast<int>((D + 255) / 256);
 #define T5VQ_PREP(NCH_)                                                                                          \
     if (compute_norms)                                                                                                 \
         hipLaunchKernelGGL((filter_prep_kernel<NCH_, true>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),    \
                            xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list, tshare);                                                               \
+                           static_cast<int>(D), n_list, tshare, row_blocks, zero);                                                               \
     else                                                                                                               \
         hipLaunchKernelGGL((filter_prep_kernel<NCH_, false>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),   \
                            xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list, tshare)
+                           static_cast<int>(D), n_list, tshare, row_blocks, zero)
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "t5vq.h"
+#include "t5vq_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1890,13 +1891,19 @@ int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, i
                          counts, embed_sum, loss_partial, false, perm, static_cast<hipStream_t>(stream));
 }
 
+static int order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work, bool work_zeroed,
+                         hipStream_t stream);
 int t5vq_order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work,
                        t5vq_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return order_by_code(keys, N, K, perm, work, false, static_cast<hipStream_t>(stream_));
+}
+
+static int order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work, bool work_zeroed,
+                         hipStream_t stream) {
     T5VQ_REQUIRE(keys && perm && work, "null pointer");
     T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
     const long long* kp = reinterpret_cast<const long long*>(keys);
-    T5VQ_CHECK_HIP(hipMemsetAsync(work, 0, static_cast<size_t>(K + 2) * 4, stream));
+    if (!work_zeroed) T5VQ_CHECK_HIP(hipMemsetAsync(work, 0, static_cast<size_t>(K + 2) * 4, stream));
     const dim3 grid(static_cast<unsigned>((N + 255) / 256));
     hipLaunchKernelGGL(code_hist_kernel, grid, dim3(256), 0, stream, kp, static_cast<int>(N), static_cast<int>(K), work);
     hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), static_cast<int>(K));
@@ -2264,18 +2271,32 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
     float* ee = reinterpret_cast<float*>(base + ws.ee);
     float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
     // index-only keys: the distance word of a token with a single candidate is an upper bound, not the distance
-    int rc = t5vq_dist_argmin_filtered_f32(x, w, xx, ee, 1, range, N, K, D, 0, 0, base + ws.total, filter_bytes, keys,
-                                           n_overflow, stream_);
+    // the search's first kernel also zeroes the statistics and the sort counters (three memset launches less)
+    const bool order = embed_sum && N >= GS_SMALL_N;
+    const bool fused_zero = (!counts || aligned16(counts)) && (!embed_sum || aligned16(embed_sum));
+    T5vqZeroArgs zero = {};
+    if (fused_zero) {
+        zero.p[0] = counts;
+        zero.n[0] = counts ? K : 0;
+        zero.p[1] = embed_sum;
+        zero.n[1] = embed_sum ? K * D : 0;
+    }
+    if (order) {
+        zero.p[2] = base + ws.work;
+        zero.n[2] = K + 2;
+    }
+    int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, 1, range, N, K, D, 0, 0, base + ws.total, filter_bytes,
+                                                keys, n_overflow, zero, stream);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
-    if (embed_sum && N >= GS_SMALL_N) {
+    if (order) {
         int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
-        rc = t5vq_order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        rc = order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), true, stream);
         if (rc != T5VQ_OK) return rc;
         perm = p;
     }
     rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
-                       partial, false, perm, stream);
+                       partial, fused_zero, perm, stream);
     if (rc != T5VQ_OK || !loss_sum) return rc;
     return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
 }
