@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         }
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_list = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        n_list[0] = 0;   // tokens left to the exact scan
+        n_list[1] = 0;   // (token, candidate) pairs left to refine_kernel
+    }
     long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     const float* src;
     _Float16* dst;
@@ -493,27 +496,26 @@ template <int L, int R>   // R scanners per lane (2 only with L = 64: up to 128 
 __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
-                                                      long long code_offset, int* __restrict__ cnt,
-                                                      int* __restrict__ cand, long long* __restrict__ keys,
+                                                      long long code_offset, int* __restrict__ pair_tok,
+                                                      int* __restrict__ pair_code, long long* __restrict__ keys,
                                                       int* __restrict__ tok_list, int* __restrict__ n_list) {
     const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
     const int tok = static_cast<int>(gid / L), s = static_cast<int>(gid % L);
-    if (tok >= N) return;   // a token's L lanes leave together: the shuffles below stay inside live groups
-    if (range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
+    // No lane leaves early: the pair counter below is reserved once per WAVE (a prefix sum over all 64 lanes).
+    bool active = tok < N;
+    if (active && range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
         const long long a = range[2 * static_cast<size_t>(tok)] - code_offset;
         const long long e = range[2 * static_cast<size_t>(tok) + 1] - code_offset;
         if ((e < K ? e : K) <= (a > 0 ? a : 0)) {
-            if (s == 0) {
-                keys[tok] = KEY_NONE;
-                cnt[tok] = 0;
-            }
-            return;
+            if (s == 0) keys[tok] = KEY_NONE;
+            active = false;
         }
     }
+    const int n_live = active ? n_scanners : 0;   // an inactive token reads nothing and ends up with no candidates
     float T = __int_as_float(0x7F800000);
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (s + r * L < n_scanners) T = fminf(T, ubuf[static_cast<size_t>(s + r * L) * N + tok]);
+        if (s + r * L < n_live) T = fminf(T, ubuf[static_cast<size_t>(s + r * L) * N + tok]);
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) T = fminf(T, __shfl_xor(T, o));
     int c[R * KEEP];
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         for (int i = 0; i < KEEP; ++i) {
             float l = 0.f;
             int ci = -1;
-            if (sc < n_scanners) {
+            if (sc < n_live) {
                 l = lbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
                 ci = cbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
             }
@@ -552,24 +554,45 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
         overflow |= __shfl_xor(overflow, o);
         f = max(f, __shfl_xor(f, o));
     }
-    int slot = incl - q;
+    // the same decision in every lane of the token
+    const bool to_scan = overflow || n > CAND_MAX || n == 0;   // n == 0: NaN / inf rows -- whatever the scan does
+    const bool decided = !to_scan && n == 1 && !exact_keys;
+    // (token, candidate) pairs go to refine_kernel as one dense list: its slots are reserved with one atomic per wave
+    // (one per token put 65536 additions on a single counter: 32 us)
+    const int lane = threadIdx.x & 63;
+    const int mine = (active && !to_scan && !decided && s == 0) ? n : 0;
+    int wincl = mine;
 #pragma unroll
-    for (int i = 0; i < R * KEEP; ++i)
-        if (ok[i]) {
-            if (slot < CAND_MAX) cand[static_cast<size_t>(tok) * CAND_MAX + slot] = c[i];
-            ++slot;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(wincl, o);
+        if (lane >= o) wincl += v;
+    }
+    const int wtotal = __shfl(wincl, 63);
+    int wbase = 0;
+    if (lane == 0 && wtotal > 0) wbase = atomicAdd(n_list + 1, wtotal);
+    wbase = __shfl(wbase, 0);
+    const int tok_base = __shfl(wbase + wincl - mine, 0, L);   // the token's first slot, from its lane 0
+    if (!active) return;
+    if (to_scan) {
+        if (s == 0) {
+            keys[tok] = KEY_NONE;               // the listed scan merges into it with atomicMin
+            tok_list[atomicAdd(n_list, 1)] = tok;
         }
-    if (s != 0) return;
-    if (overflow || n > CAND_MAX || n == 0) {   // n == 0: NaN / inf rows -- whatever the scan does with them
-        keys[tok] = KEY_NONE;                   // the listed scan merges into it with atomicMin
-        tok_list[atomicAdd(n_list, 1)] = tok;
-        cnt[tok] = 0;
-    } else if (n == 1 && !exact_keys) {         // the index is decided; T_i (an upper bound of its distance) fills
-        const long long gi = code_offset + f - (range ? range[2 * static_cast<size_t>(tok)] : 0);
-        keys[tok] = pack_key(T, static_cast<int>(gi));   // the key's distance word (index: slice-relative if ranged)
-        cnt[tok] = 0;
-    } else {
-        cnt[tok] = n;
+    } else if (decided) {                       // the index is decided; T_i (an upper bound of its distance) fills
+        if (s == 0) {
+            const long long gi = code_offset + f - (range ? range[2 * static_cast<size_t>(tok)] : 0);
+            keys[tok] = pack_key(T, static_cast<int>(gi));   // the key's distance word (index: slice-relative if ranged)
+        }
+    } else {   // refine_kernel merges the pairs' exact keys into the token's key with atomicMin
+        if (s == 0) keys[tok] = KEY_NONE;
+        int slot = tok_base + incl - q;
+#pragma unroll
+        for (int i = 0; i < R * KEEP; ++i)
+            if (ok[i]) {
+                pair_tok[slot] = tok;
+                pair_code[slot] = c[i];
+                ++slot;
+            }
     }
 }
 
@@ -601,32 +624,32 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ xr, co
     return fmaf(-2.0f, dot, xxv + eev);
 }
 
-// ---- refine: one lane per (token, candidate slot); a token's CAND_MAX lanes sit side by side ------------------
+// ---- refine: one lane per (token, candidate) pair of the dense list collect_kernel wrote; the exact distances merge
+// into the token's key with atomicMin (lowest distance, then lowest index: the scan's rule).  With one lane per
+// (token, slot) -- 16 slots per token, 2 or 3 in use -- a batch where most tokens keep two candidates ran 16384 waves
+// of 768-long fma chains at 15 % lane use (cold / collapsed regimes: 84 us); the host does not know the pair count,
+// so a fixed grid strides over the list.
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ xx, const float* __restrict__ ee,
-                                                     int N, int K, int D, const long long* __restrict__ range,
-                                                     long long code_offset, const int* __restrict__ cnt,
-                                                     const int* __restrict__ cand, long long* __restrict__ keys) {
-    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-    const int tok = static_cast<int>(gid / CAND_MAX);
-    const int slot = static_cast<int>(gid % CAND_MAX);
-    long long key = KEY_NONE;
-    int n = 0;
-    if (tok < N) {
-        n = cnt[tok];
-        if (slot < n) {
-            const int code = cand[static_cast<size_t>(tok) * CAND_MAX + slot];
-            const long long gi = code_offset + code - (range ? range[2 * static_cast<size_t>(tok)] : 0);
-            key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D, w + static_cast<size_t>(code) * D, D,
-                                          xx[tok], ee[code]), static_cast<int>(gi));
-        }
+                                                     int D, const long long* __restrict__ range,
+                                                     long long code_offset, const int* __restrict__ n_pairs,
+                                                     const int* __restrict__ pair_tok,
+                                                     const int* __restrict__ pair_code, long long* __restrict__ keys) {
+    // about 16 pairs per wave while the list is short (a dense wave touches 64 rows per load: few waves would carry
+    // the whole list on a few CUs), all 64 lanes once every wave of the grid has that many
+    const int n = *n_pairs;
+    const int n_waves = gridDim.x * 4;
+    int w_eff = (n + 15) / 16;
+    w_eff = w_eff < 1 ? 1 : (w_eff > n_waves ? n_waves : w_eff);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave >= w_eff) return;
+    for (long long p = static_cast<long long>(lane) * w_eff + wave; p < n; p += 64LL * w_eff) {
+        const int tok = pair_tok[p], code = pair_code[p];
+        const long long gi = code_offset + code - (range ? range[2 * static_cast<size_t>(tok)] : 0);
+        const long long key = pack_key(exact_distance(x + static_cast<size_t>(tok) * D, w + static_cast<size_t>(code) * D,
+                                                      D, xx[tok], ee[code]), static_cast<int>(gi));
+        atomicMin(keys + tok, key);
     }
-#pragma unroll
-    for (int o = 1; o < CAND_MAX; o <<= 1) {
-        const long long other = __shfl_xor(key, o);
-        key = other < key ? other : key;
-    }
-    if (tok < N && slot == 0 && n > 0) keys[tok] = key;
 }
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -641,8 +664,8 @@ struct FilterWorkspace {
         ubuf = align_up(winv + 4 * t5vq_padded_codes(K), 256);
         lbuf = align_up(ubuf + 4 * N * scanners, 256);
         cbuf = align_up(lbuf + 4 * N * scanners * KEEP, 256);
-        cnt = align_up(cbuf + 4 * N * scanners * KEEP, 256);
-        cand = align_up(cnt + 4 * N, 256);
+        cnt = align_up(cbuf + 4 * N * scanners * KEEP, 256);       // pair list: token ids  [N * CAND_MAX]
+        cand = align_up(cnt + 4 * N * CAND_MAX, 256);              // pair list: codes      [N * CAND_MAX]
         list = align_up(cand + 4 * N * CAND_MAX, 256);
         nlist = align_up(list + 4 * N, 256);
         tshare = align_up(nlist + 64, 256);                 // int32 [N]: smallest upper bound any scanner has seen
@@ -801,9 +824,10 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     else { T5VQ_COLLECT(64, 2); }
 #undef T5VQ_COLLECT
     T5VQ_I_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>((N * CAND_MAX + 255) / 256)), dim3(256), 0, stream, x, w,
-                       xx, ee, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), rg,
-                       static_cast<long long>(code_offset), cnt, cand, reinterpret_cast<long long*>(keys));
+    const int64_t refine_blocks = (N * CAND_MAX + 255) / 256 < 2048 ? (N * CAND_MAX + 255) / 256 : 2048;
+    hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>(refine_blocks)), dim3(256), 0, stream, x, w, xx, ee,
+                       static_cast<int>(D), rg, static_cast<long long>(code_offset), n_list + 1, cnt, cand,
+                       reinterpret_cast<long long*>(keys));
     T5VQ_I_CHECK_HIP(hipGetLastError());
     // tokens the filter could not settle: the fp32 scan kernel itself, on those tokens only
     const int rc = t5vq_internal_scan_listed(x, w, xx, ee, range, N, K, D, code_offset, tok_list, n_list, keys, stream);
