@@ -492,16 +492,41 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 // L lanes per token, one per scanner (L = 4, 8, 16, 32 >= n_scanners): with one thread per token a small batch with
 // many code splits walked 32 x 9 dependent loads in 12 workgroups (C1: 76 us).  Candidates keep the (scanner, slot)
 // order through a prefix sum over the token's lanes (any order would do: refine takes the packed-key minimum).
+constexpr int COLLECT_THREADS = 1024;
+// Every thread of the workgroup asks for `mine` consecutive slots of a list whose length lives in *counter: one
+// atomic per workgroup (additions to one word from all XCDs serialise at about 10 ns each: one per wave cost 32 us
+// at C3).  Returns the thread's first slot.  All threads of the workgroup must call it.
+__device__ __forceinline__ int block_reserve(int mine, int* counter, int* s_wave_total, int* s_block_base) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    __syncthreads();   // the previous use of the two shared words is over
+    if (lane == 63) s_wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int i = 0; i < COLLECT_THREADS / 64; ++i) total += s_wave_total[i];
+        *s_block_base = total > 0 ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int base = *s_block_base;
+    for (int i = 0; i < wave; ++i) base += s_wave_total[i];
+    return base + incl - mine;
+}
 template <int L, int R>   // R scanners per lane (2 only with L = 64: up to 128 scanners)
-__global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
+__global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
                                                       long long code_offset, int* __restrict__ pair_tok,
                                                       int* __restrict__ pair_code, long long* __restrict__ keys,
                                                       int* __restrict__ tok_list, int* __restrict__ n_list) {
-    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    const long long gid = static_cast<long long>(blockIdx.x) * COLLECT_THREADS + threadIdx.x;
     const int tok = static_cast<int>(gid / L), s = static_cast<int>(gid % L);
-    // No lane leaves early: the pair counter below is reserved once per WAVE (a prefix sum over all 64 lanes).
+    // No lane leaves early: the pair counter below is reserved once per WORKGROUP (prefix sums over all its lanes).
     bool active = tok < N;
     if (active && range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
         const long long a = range[2 * static_cast<size_t>(tok)] - code_offset;
@@ -557,26 +582,17 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
     // the same decision in every lane of the token
     const bool to_scan = overflow || n > CAND_MAX || n == 0;   // n == 0: NaN / inf rows -- whatever the scan does
     const bool decided = !to_scan && n == 1 && !exact_keys;
-    // (token, candidate) pairs go to refine_kernel as one dense list: its slots are reserved with one atomic per wave
-    // (one per token put 65536 additions on a single counter: 32 us)
-    const int lane = threadIdx.x & 63;
-    const int mine = (active && !to_scan && !decided && s == 0) ? n : 0;
-    int wincl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(wincl, o);
-        if (lane >= o) wincl += v;
-    }
-    const int wtotal = __shfl(wincl, 63);
-    int wbase = 0;
-    if (lane == 0 && wtotal > 0) wbase = atomicAdd(n_list + 1, wtotal);
-    wbase = __shfl(wbase, 0);
-    const int tok_base = __shfl(wbase + wincl - mine, 0, L);   // the token's first slot, from its lane 0
+    // (token, candidate) pairs go to refine_kernel as one dense list, unsettled tokens to the scan's list
+    __shared__ int s_wave_total[COLLECT_THREADS / 64], s_block_base;
+    const bool lead = active && s == 0;
+    const int pair_slot = block_reserve(lead && !to_scan && !decided ? n : 0, n_list + 1, s_wave_total, &s_block_base);
+    const int list_slot = block_reserve(lead && to_scan ? 1 : 0, n_list, s_wave_total, &s_block_base);
+    const int tok_base = __shfl(pair_slot, 0, L);   // the token's first pair slot, from its lane 0
     if (!active) return;
     if (to_scan) {
         if (s == 0) {
             keys[tok] = KEY_NONE;               // the listed scan merges into it with atomicMin
-            tok_list[atomicAdd(n_list, 1)] = tok;
+            tok_list[list_slot] = tok;
         }
     } else if (decided) {                       // the index is decided; T_i (an upper bound of its distance) fills
         if (s == 0) {
@@ -811,7 +827,9 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
 #undef T5VQ_FILTER_ARGS
     T5VQ_I_CHECK_HIP(hipGetLastError());
 #define T5VQ_COLLECT(L_, R_)                                                                                      \
-    hipLaunchKernelGGL((collect_kernel<L_, R_>), dim3(static_cast<unsigned>((N * L_ + 255) / 256)), dim3(256), 0, stream,  \
+    hipLaunchKernelGGL((collect_kernel<L_, R_>),                                                                   \
+                       dim3(static_cast<unsigned>((N * L_ + COLLECT_THREADS - 1) / COLLECT_THREADS)),                   \
+                       dim3(COLLECT_THREADS), 0, stream,                                                             \
                        ubuf, lbuf, cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners),      \
                        exact_keys, rg, static_cast<long long>(code_offset), cnt, cand,                               \
                        reinterpret_cast<long long*>(keys), tok_list, n_list)
