@@ -121,7 +121,8 @@ class _QuantizerBase(nn.Module):
     # "auto": filter when it applies (D % 64 == 0) and pays (N*K >= filter_min_work), with a
     # back-off to the scan while the filter leaves too many tokens unsettled (degenerate codebooks: all rows equal).
     search = "auto"
-    filter_min_work = 1 << 24    # N*K below which the scan is faster (C2: 2e6 -> scan; C1: 2.9e7 -> filter)
+    filter_min_work = 1 << 23    # N*K from which the filter pays (tools/bench_crossover.py: 0.85x at 2^21, 1.15x at
+                                 # 2^22, 1.7x at 2^23, 2.8x at 2^24; C2: 2e6 -> scan, C1: 2.9e7 -> filter)
     filter_backoff_calls = 32    # calls to stay on the scan after a call with > 1/8 of the tokens unsettled
     # EMA statistics.  False: embed_sum by fp32 atomics (fastest; last bits depend on arrival order).  True: 64-bit
     # fixed-point sums (t5vq_embed_sum_fixed_f32): bit-reproducible from run to run and for any token sharding, and
