@@ -648,12 +648,15 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ xr, co
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ xx, const float* __restrict__ ee,
                                                      int D, const long long* __restrict__ range,
-                                                     long long code_offset, const int* __restrict__ n_pairs,
+                                                     long long code_offset, const int* __restrict__ counters,
                                                      const int* __restrict__ pair_tok,
-                                                     const int* __restrict__ pair_code, long long* __restrict__ keys) {
+                                                     const int* __restrict__ pair_code, long long* __restrict__ keys,
+                                                     int* __restrict__ n_overflow) {
+    // the caller's copy of the unsettled-token count (collect_kernel is complete: saves a copy launch)
+    if (n_overflow && blockIdx.x == 0 && threadIdx.x == 0) *n_overflow = counters[0];
     // about 16 pairs per wave while the list is short (a dense wave touches 64 rows per load: few waves would carry
     // the whole list on a few CUs), all 64 lanes once every wave of the grid has that many
-    const int n = *n_pairs;
+    const int n = counters[1];   // counters: [0] tokens left to the scan, [1] pairs
     const int n_waves = gridDim.x * 4;
     int w_eff = (n + 15) / 16;
     w_eff = w_eff < 1 ? 1 : (w_eff > n_waves ? n_waves : w_eff);
@@ -844,13 +847,12 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     T5VQ_I_CHECK_HIP(hipGetLastError());
     const int64_t refine_blocks = (N * CAND_MAX + 255) / 256 < 2048 ? (N * CAND_MAX + 255) / 256 : 2048;
     hipLaunchKernelGGL(refine_kernel, dim3(static_cast<unsigned>(refine_blocks)), dim3(256), 0, stream, x, w, xx, ee,
-                       static_cast<int>(D), rg, static_cast<long long>(code_offset), n_list + 1, cnt, cand,
-                       reinterpret_cast<long long*>(keys));
+                       static_cast<int>(D), rg, static_cast<long long>(code_offset), n_list, cnt, cand,
+                       reinterpret_cast<long long*>(keys), n_overflow);
     T5VQ_I_CHECK_HIP(hipGetLastError());
     // tokens the filter could not settle: the fp32 scan kernel itself, on those tokens only
     const int rc = t5vq_internal_scan_listed(x, w, xx, ee, range, N, K, D, code_offset, tok_list, n_list, keys, stream);
     if (rc != T5VQ_OK) return rc;
-    if (n_overflow) T5VQ_I_CHECK_HIP(hipMemcpyAsync(n_overflow, n_list, 4, hipMemcpyDeviceToDevice, stream));
     return T5VQ_OK;
 }
 
