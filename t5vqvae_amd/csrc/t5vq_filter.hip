@@ -434,10 +434,12 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 #pragma unroll
                     for (int b = 0; b < TB; ++b) {
                         float dm = __int_as_float(0x7F800000);
+                        float sv[4], dv[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float s = xv[b] + e4[c];
-                            float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);   // -2 dot~, rescaled exactly
+                            sv[c] = xv[b] + e4[c];
+                            dv[c] = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], sv[c]);   // -2 dot~, rescaled exactly
+                            float d = dv[c];
                             if (RANGED) d = (cb + c >= ls[b] && cb + c < le[b]) ? d : __int_as_float(0x7F800000);
                             dm = fminf(dm, d);
                         }
@@ -450,9 +452,8 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                         const f32x4 s4 = *reinterpret_cast<const f32x4*>(ep_s + 4 * h + 8 * g4);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float s = xv[b] + e4[c];
-                            const float d = fmaf(acc[b][t][g4 * 4 + c] * m2[b], i4[c], s);
-                            const float delta = fmaf(csx[b], s4[c], r * s);
+                            const float d = dv[c];
+                            const float delta = fmaf(csx[b], s4[c], r * sv[c]);
                             float up = d + delta;                        // padded codes: +inf
                             float lo = d - delta;                        // padded codes: inf - inf = NaN
                             if (RANGED) {
