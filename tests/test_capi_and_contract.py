@@ -44,6 +44,13 @@ def test_invalid_arguments_are_rejected_before_any_launch():
                                      None, None) == 1                               # D > 2048
     assert lib.t5vq_order_by_code(p, 4, 4, None, p, None) == 1
     assert lib.t5vq_ema_cluster_f32(None, p, None, 4, 4, 1.0, .99, .01, 1e-5, 4e-5, .25, 0, 9, p, None) == 1
+    # composite forwards: workspace checks come before any launch
+    assert lib.t5vq_vq_forward_f32(p, p, None, None, 4, 4, 8, 0, None, 0, None, None, None, None, None, None, None,
+                                   None) == 1
+    assert lib.t5vq_forward_filtered_workspace_bytes(4096, 512, 768) > lib.t5vq_forward_workspace_bytes(4096, 512)
+    assert lib.t5vq_vq_forward_filtered_f32(p, p, None, 4, 4, 64, 0, None, 0, None, None, None, None, None, None, None,
+                                            None, None) == 1
+    assert b"workspace" in lib.t5vq_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
