@@ -814,6 +814,21 @@ __device__ __forceinline__ unsigned long long same_code_lanes(int code, bool val
     *n_distinct = distinct;
     return mine;
 }
+// exclusive prefix of `local` over the threads of a workgroup (<= 1024): wave scans by shuffles, wave totals through LDS
+__device__ __forceinline__ int block_exclusive_scan(int local, int* s_wave /*[16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < wave; ++i) before += s_wave[i];
+    return before + incl - local;
+}
 // work layout: [0, K) counters / cursors, [K] groups of the plain walk, [K+1] 1 = order the tokens, 0 = identity
 __global__ __launch_bounds__(256) void code_hist_kernel(const long long* __restrict__ keys, int N, int K,
                                                         int* __restrict__ work) {
@@ -833,7 +848,7 @@ __global__ __launch_bounds__(256) void code_hist_kernel(const long long* __restr
     if (threadIdx.x == 0) atomicAdd(work + K, s_groups);
 }
 __global__ __launch_bounds__(1024) void code_scan_kernel(int* __restrict__ work, int N, int K) {  // in place: exclusive scan
-    __shared__ int s_sum[1024];
+    __shared__ int s_wave[16];
     __shared__ int s_used[16];
     const int per = (K + 1023) / 1024;
     const int b = threadIdx.x * per;
@@ -844,17 +859,9 @@ __global__ __launch_bounds__(1024) void code_scan_kernel(int* __restrict__ work,
             local += c;
             used += c > 0;
         }
-    s_sum[threadIdx.x] = local;
     used = static_cast<int>(wave_sum(static_cast<float>(used)));   // <= 64 * per: exact in fp32
     if ((threadIdx.x & 63) == 0) s_used[threadIdx.x >> 6] = used;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = s_sum[threadIdx.x] - local;
+    int run = block_exclusive_scan(local, s_wave);
     for (int i = 0; i < per; ++i)
         if (b + i < K) {
             const int c = work[b + i];
