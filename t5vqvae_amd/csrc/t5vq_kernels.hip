@@ -983,16 +983,35 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
                 qq += q[j].x * q[j].x + q[j].y * q[j].y + q[j].z * q[j].z + q[j].w * q[j].w;
             qq = wave_sum(qq);
         }
-        while (m) {
-            const int t = __ffsll(static_cast<long long>(m)) - 1;
-            m &= m - 1;
-            const size_t rowoff = static_cast<size_t>(s_tok[t]) * D;
-            const f32x4* xr = reinterpret_cast<const f32x4*>(x + rowoff);
-            f32x4 xv[NCH];
+        // the next member's row is requested before the current one is processed (a run of equal codes is a chain of
+        // 3 KB rows from all over x: one row in flight per wave left the loads' latency in the open)
+        f32x4 xn[NCH];
+        int tn = __ffsll(static_cast<long long>(m)) - 1;
+        m &= m - 1;
+        {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<size_t>(s_tok[tn]) * D);
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c4 = j * 64 + lane;
-                xv[j] = (c4 * 4 < D) ? xr[c4] : zero4;
+                xn[j] = (c4 * 4 < D) ? xr[c4] : zero4;
+            }
+        }
+        while (tn >= 0) {
+            const int t = tn;
+            const size_t rowoff = static_cast<size_t>(s_tok[t]) * D;
+            f32x4 xv[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) xv[j] = xn[j];
+            tn = -1;
+            if (m) {
+                tn = __ffsll(static_cast<long long>(m)) - 1;
+                m &= m - 1;
+                const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<size_t>(s_tok[tn]) * D);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int c4 = j * 64 + lane;
+                    xn[j] = (c4 * 4 < D) ? xr[c4] : zero4;
+                }
             }
             float pd = 0.f, px = 0.f;
             // ordered tokens: which tokens share a workgroup varies from run to run, so the loss is kept per TOKEN
