@@ -261,6 +261,23 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
                         float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
                         t5vq_stream_t stream);
 
+/* t5vq_vq_forward_f32 for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
+ * that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it -- and
+ * so cannot bring the workspace the entry point above asks for.  Same arguments minus the workspace, same kernels,
+ * same results; the per-call temporaries (keys, |x|^2, |e|^2, loss terms, token order, sort cursors) live in a
+ * library-owned static device array of T5VQ_NOALLOC_SCRATCH_BYTES (one copy per GPU the library runs on, held until
+ * the process ends; its device address is looked up once per device on the first call there, with that device
+ * current).  The call allocates and frees nothing.  Limit: t5vq_forward_workspace_bytes(N, K) (about 20 N + 8 K bytes)
+ * must not exceed T5VQ_NOALLOC_SCRATCH_BYTES -- e.g. N = 131072 with K = 16384, or N = 65536 with K = 65536;
+ * larger shapes return T5VQ_ERR_INVALID with a message.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (two streams, two host threads) race on it -- serialise them; calls on one stream are ordered
+ * by the stream.  Nothing is carried from one call to the next (every temporary is rewritten before it is read). */
+#define T5VQ_NOALLOC_SCRATCH_BYTES (4 << 20)
+int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
+                                int64_t K, int64_t D, int loss_kind, float* out_ste, float* out_q, float* out_diff,
+                                int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                                t5vq_stream_t stream);
+
 /* The same forward (vqvae/vqvae.py:103-128,147-152,160 + :133,:141) with the filtered search of
  * t5vq_dist_argmin_filtered_f32 in place of the scan: identical indices and outputs, one host call.  Needs
  * D % 64 == 0, 64 <= D <= 4096.  workspace: t5vq_forward_filtered_workspace_bytes(N, K, D) bytes, 256-byte aligned.

@@ -49,6 +49,7 @@ SIGNATURES = {
     "t5vq_rmsnorm_backward_f32": (c_int, [P, P, P, P, c_float, P, I64, I64, P, P, P, P]),
     "t5vq_forward_workspace_bytes": (I64, [I64, I64]),
     "t5vq_vq_forward_f32": (c_int, [P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P]),
+    "t5vq_vq_forward_noalloc_f32": (c_int, [P, P, P, P, I64, I64, I64, c_int, P, P, P, P, P, P, P, P]),
     "t5vq_forward_filtered_workspace_bytes": (I64, [I64, I64, I64]),
     "t5vq_vq_forward_filtered_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P]),
     "t5vq_vq_ema_finalize_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, c_float, c_float, c_float, c_float,

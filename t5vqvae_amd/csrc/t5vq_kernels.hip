@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "t5vq.h"
@@ -2228,15 +2229,11 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
 
 // Launches: [row norms + buffer preparation] -> [distance + argmin] -> ([order tokens by code: 3 small launches],
 // training with N >= 32768) -> [gather + statistics] -> [loss sum].
-int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
-                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
-                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                        t5vq_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+static int vq_forward_impl(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
+                           int64_t K, int64_t D, int loss_kind, void* workspace, float* out_ste, float* out_q,
+                           float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                           hipStream_t stream) {
     const FwdWorkspace ws(N, K);
-    T5VQ_REQUIRE(workspace && aligned16(workspace), "workspace null or not 16-byte aligned");
-    T5VQ_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
     T5VQ_REQUIRE(x && w, "null input");
     char* base = static_cast<char*>(workspace);
     int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
@@ -2269,6 +2266,67 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
                        partial, true, perm, stream);
     if (rc != T5VQ_OK || !loss_sum) return rc;
     return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
+}
+
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
+                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                        t5vq_stream_t stream_) {
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    T5VQ_REQUIRE(workspace && aligned16(workspace), "workspace null or not 16-byte aligned");
+    T5VQ_REQUIRE(workspace_bytes >= FwdWorkspace(N, K).total, "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
+    return vq_forward_impl(x, w, range, xx_in, N, K, D, loss_kind, workspace, out_ste, out_q, out_diff, idx_out, counts,
+                           embed_sum, loss_sum, static_cast<hipStream_t>(stream_));
+}
+
+// ---- The forward for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the per-call temporaries of t5vq_vq_forward_f32 (keys, |x|^2, |e|^2, loss terms, token order, sort
+// cursors) live in ONE file-scope device array instead of a caller-brought workspace.  Every GPU the library runs on
+// holds its own copy of the array, at its own address, until the process ends.
+static __device__ __align__(256) unsigned char scratch[T5VQ_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+// In host code `scratch` is only a stand-in for the symbol: the device address of each GPU's copy is looked up once
+// per device (with that device current) and kept here; only these pointers ever reach a kernel, memset or copy.
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[64] = {nullptr};
+
+int scratch_for_current_device(void** out) {
+    int dev = 0;
+    T5VQ_CHECK_HIP(hipGetDevice(&dev));
+    T5VQ_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        T5VQ_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        T5VQ_REQUIRE(ptr && (reinterpret_cast<uintptr_t>(ptr) & 255u) == 0, "scratch symbol null or misaligned");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return T5VQ_OK;
+}
+}  // namespace
+
+int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
+                                int64_t K, int64_t D, int loss_kind, float* out_ste, float* out_q, float* out_diff,
+                                int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+                                t5vq_stream_t stream_) {
+    T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
+    T5VQ_REQUIRE(N < (1LL << 31) && K < (1LL << 31), "N or K too large");
+    if (FwdWorkspace(N, K).total > static_cast<int64_t>(T5VQ_NOALLOC_SCRATCH_BYTES)) {
+        char need[64];
+        snprintf(need, sizeof(need), "%lld", static_cast<long long>(FwdWorkspace(N, K).total));
+        return fail(T5VQ_ERR_INVALID,
+                    "t5vq_vq_forward_noalloc_f32: N, K need %s bytes of temporaries, the static scratch holds "
+                    "T5VQ_NOALLOC_SCRATCH_BYTES%s", need, " (use t5vq_vq_forward_f32 with a workspace)");
+    }
+    void* ptr = nullptr;
+    const int rc = scratch_for_current_device(&ptr);
+    if (rc != T5VQ_OK) return rc;
+    // every temporary is (re)written before it is read: keys are filled with 'none' and the statistics zeroed by the
+    // first launch, the sort cursors by a memset on `stream`; nothing of the previous call's contents is used
+    return vq_forward_impl(x, w, range, xx_in, N, K, D, loss_kind, ptr, out_ste, out_q, out_diff, idx_out, counts,
+                           embed_sum, loss_sum, static_cast<hipStream_t>(stream_));
 }
 
 // The same forward with the filtered search (t5vq_filter.hip) in place of the scan: [fp16 images + row norms] ->

@@ -1,0 +1,87 @@
+"""t5vq_vq_forward_noalloc_f32 (include/t5vq.h): the forward for callers that cannot allocate, against
+t5vq_vq_forward_f32 with a caller-brought workspace.  Both run the same kernels, so indices, straight-through
+output, q - x, the loss sum and the counts must be bit-identical; embed_sum is accumulated with fp32 atomics whose
+arrival order differs from launch to launch, so it is compared at 1e-6 norm-wise (the bar of every EMA-buffer test
+here is 1e-5).  Two calls in a row, the second with a smaller input (the static scratch keeps the first call's
+contents); a shape beyond the scratch is refused with a message.  Runs last (file name): the round's end runs
+pytest -x."""
+import ctypes
+
+import pytest
+import torch
+
+from t5vqvae_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _outputs(n, k, d, dev):
+    return {"ste": torch.full((n, d), float("nan"), device=dev), "diff": torch.full((n, d), float("nan"), device=dev),
+            "idx": torch.full((n,), -1, dtype=torch.int64, device=dev),
+            "counts": torch.full((k,), float("nan"), device=dev),
+            "embed_sum": torch.full((k, d), float("nan"), device=dev),
+            "loss_sum": torch.full((1,), float("nan"), device=dev)}
+
+
+def _run(lib, x, w, ranges, noalloc):
+    n, d = x.shape
+    k = w.shape[0]
+    o = _outputs(n, k, d, x.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tail = (_p(o["ste"]), None, _p(o["diff"]), _p(o["idx"]), _p(o["counts"]), _p(o["embed_sum"]), _p(o["loss_sum"]),
+            stream)
+    if noalloc:
+        rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(w), _p(ranges), None, n, k, d, 0, *tail)
+    else:
+        nbytes = int(lib.t5vq_forward_workspace_bytes(n, k))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        rc = lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), None, n, k, d, 0, _p(ws), nbytes, *tail)
+    _lib.check(rc, "noalloc" if noalloc else "workspace")
+    torch.cuda.synchronize()
+    return o
+
+
+def _compare(a, b):
+    for name in ("idx", "ste", "diff", "loss_sum", "counts"):
+        assert torch.equal(a[name], b[name]), name
+    err = float((a["embed_sum"].double() - b["embed_sum"].double()).norm() / b["embed_sum"].double().norm())
+    assert err <= 1e-6, f"embed_sum differs by {err}"
+    assert float(a["counts"].sum()) == a["idx"].numel()
+
+
+def test_noalloc_forward_equals_workspace_forward_twice():
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    d = 768
+    # first call: enough tokens for the ordered statistics walk (every region of the scratch is used);
+    # second call: smaller N AND smaller K, the ranged search, no token ordering -- over the first call's leftovers
+    cases = [(40000, 1000, None), (1500, 300, [(0, 100), (100, 300), (20, 250)])]
+    for i, (n, k, roles) in enumerate(cases):
+        x = synth.normal((n, d), 70 + i, 0).to(dev)
+        w = synth.normal((k, d), 70 + i, 1).to(dev)
+        ranges = None if roles is None else synth.role_ranges(n, roles, 70 + i, 2).to(dev).contiguous()
+        got = _run(lib, x, w, ranges, noalloc=True)
+        want = _run(lib, x, w, ranges, noalloc=False)
+        _compare(got, want)
+    # and the first shape once more after the small one
+    n, k, _ = cases[0]
+    x = synth.normal((n, d), 70, 0).to(dev)
+    w = synth.normal((k, d), 70, 1).to(dev)
+    _compare(_run(lib, x, w, None, noalloc=True), _run(lib, x, w, None, noalloc=False))
+
+
+def test_noalloc_forward_refuses_shapes_beyond_the_scratch():
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, k, d = 1 << 20, 16384, 768          # 20 N + 8 K = 21 MB of temporaries > 4 MiB; refused before any launch
+    assert int(lib.t5vq_forward_workspace_bytes(n, k)) > (4 << 20)
+    x = torch.empty(16, d, device=dev)     # never dereferenced: the size check comes first
+    rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(x), None, None, n, k, d, 0, None, None, None, None, None, None, None,
+                                         None)
+    assert rc == 1
+    msg = lib.t5vq_last_error().decode()
+    assert "T5VQ_NOALLOC_SCRATCH_BYTES" in msg and "t5vq_vq_forward_f32" in msg
