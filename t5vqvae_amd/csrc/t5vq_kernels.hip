@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -1641,10 +1642,11 @@ template <class C, bool V2 = false>
 int launch_dist_cfg(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
                            int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
                            float* dist, hipStream_t stream, const DistOpts& opts = DistOpts()) {
-    static bool attr_done[64] = {false};
+    // per (tile configuration, device) once; two host threads that race here both set the same attributes (idempotent)
+    static std::atomic<bool> attr_done[64];
     int dev = 0;
     T5VQ_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, false, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_kernel<C, true, false>),
@@ -1667,7 +1669,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
             T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, true, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         }
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
