@@ -85,13 +85,14 @@ int main(int argc, char** argv) {
     VQ_OK(t5vq_dist_argmin_filtered_f32(x, w, xx, ee, /*compute_norms=*/1, /*range=*/nullptr, N, K, D, /*code_offset=*/0,
                                         /*exact_keys=*/1, ws_f, wsf_bytes, keys_f, unsettled, stream));
     // forward: indices, straight-through output, loss terms, EMA statistics (vqvae/vqvae.py:103-160)
-    VQ_OK(t5vq_vq_forward_f32(x, w, nullptr, nullptr, N, K, D, T5VQ_LOSS_MSE, ws, ws_bytes, ste, nullptr, nullptr, idx,
-                              counts, embed_sum, loss_sum, stream));
+    VQ_OK(t5vq_vq_forward_f32(x, w, nullptr, /*xx_in=*/nullptr, /*ee_in=*/nullptr, N, K, D, T5VQ_LOSS_MSE, ws, ws_bytes,
+                              ste, nullptr, nullptr, idx, counts, embed_sum, /*loss_terms=*/nullptr, loss_sum, stream));
     // (a token-sharded job all-reduces `stats` here)
     // finalize: cluster sizes, Laplace smoothing, codebook, loss and perplexity (vqvae/vqvae.py:131-162)
-    VQ_OK(t5vq_vq_ema_finalize_f32(cs, ema_w, w, counts, embed_sum, loss_sum, K, D, N, static_cast<float>(N * D), decay,
-                                   static_cast<float>(1.0 - 0.99), eps, static_cast<float>(K * 1e-5), cc, 0, 1, scalars,
-                                   stream));
+    // (ee_out = ee: the norms of the codebook just written, ready to be the next step's ee_in)
+    VQ_OK(t5vq_vq_ema_finalize_f32(cs, ema_w, w, counts, embed_sum, loss_sum, /*n_loss_terms=*/1, K, D, N,
+                                   static_cast<float>(N * D), decay, static_cast<float>(1.0 - 0.99), eps,
+                                   static_cast<float>(K * 1e-5), cc, 0, 1, scalars, /*ee_out=*/ee, stream));
     HIP_OK(hipStreamSynchronize(stream));
 
     std::vector<int64_t> hidx(N), hkeys(N);

@@ -130,16 +130,23 @@ int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, 
  * around one scalar all-reduce:  mode 2 writes cs <- cs*decay + one_minus_decay*counts and the LOCAL
  * partial sums scalars[1] = sum p log(p + 1e-10), scalars[2] = sum cs;  the caller all-reduces
  * scalars[1..2];  mode 3 reads them back, applies the Laplace smoothing and writes the perplexity.
- * In modes 2 and 3 cluster_size may be NULL (evaluation: only the perplexity is assembled). */
-int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t K,
-                         int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
-                         float k_epsilon, float commitment_cost, int plain_variant, int mode, float* scalars,
-                         t5vq_stream_t stream);
+ * In modes 2 and 3 cluster_size may be NULL (evaluation: only the perplexity is assembled).
+ * loss_sum[0 .. n_loss_terms) are added up by this kernel (fixed order, fp64 accumulation -- the order of
+ * t5vq_reduce_partials_f32, bit-identical to it): n_loss_terms = 1 for a ready sum, or the forward's unreduced loss
+ * terms (t5vq_vq_forward_f32's loss_terms), which saves the reduce launch. */
+int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t n_loss_terms,
+                         int64_t K, int64_t n_tokens, float loss_denom, float decay, float one_minus_decay,
+                         float epsilon, float k_epsilon, float commitment_cost, int plain_variant, int mode,
+                         float* scalars, t5vq_stream_t stream);
 
 /* Codebook EMA: ema_w <- ema_w*decay + one_minus_decay*embed_sum;  w <- ema_w / cluster_size[:,None]
- * (vqvae/vqvae.py:141-144; in place instead of re-binding new Parameters). */
+ * (vqvae/vqvae.py:141-144; in place instead of re-binding new Parameters).
+ * ee_out (nullable, [>= K]): |e_k|^2 of the codebook just written, bit-identical to t5vq_row_sqnorms_f32 run on it
+ * (same lane layout and order, taken from the values in registers): the next forward can take it as ee_in instead of
+ * re-reading the codebook (vqvae/vqvae.py:107 recomputes the norms every call).  Only rows < K are written: the
+ * +inf padding of a t5vq_padded_codes(K) buffer is the caller's to set once (t5vq_row_sqnorms_f32 does). */
 int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
-                       int64_t D, float decay, float one_minus_decay, t5vq_stream_t stream);
+                       int64_t D, float decay, float one_minus_decay, float* ee_out, t5vq_stream_t stream);
 
 /* ---- Order-independent EMA statistics (opt-in; no reference counterpart: the reference's matmul(encodings.t(),
  * flat_input), vqvae/vqvae.py:141, is deterministic on its CPU path, float atomics are not) ----------------------
@@ -150,14 +157,14 @@ int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const flo
  *                             MAX, as int32, so that every rank uses the same scale)
  *   t5vq_embed_sum_fixed_f32: embed_sum[k - stats_begin, :] = sum_{i : idx_i = k} round(x_i * 2^s)   (int64 [.,D],
  *                             zeroed by the call; N < 2^24, D <= 1024)
- *   t5vq_ema_embed_fixed_f32: t5vq_ema_embed_f32 with dw = float(embed_sum * 2^-s). */
+ *   t5vq_ema_embed_fixed_f32: t5vq_ema_embed_f32 with dw = float(embed_sum * 2^-s) (ee_out as there). */
 int t5vq_max_norm_f32(const float* xx, int64_t N, int32_t* max_xx_bits, t5vq_stream_t stream);
 int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t* max_xx_bits, int64_t N, int64_t K,
                              int64_t D, int64_t stats_begin, int64_t stats_count, int64_t* embed_sum,
                              t5vq_stream_t stream);
 int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
                              const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
-                             t5vq_stream_t stream);
+                             float* ee_out, t5vq_stream_t stream);
 
 /* Gradient of the straight-through output and the MSE commitment term with respect to the inputs:
  *   grad_x = g_out - diff * (g_loss[0] * coef),  diff = q - x,  coef = commitment_cost * 2 / (N*D)
@@ -194,9 +201,11 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
  * exact_keys != 0: keys are bit-identical to t5vq_dist_argmin_f32's.  exact_keys == 0: the INDEX word is identical;
  * for a token with a single candidate the distance word holds an upper bound instead of the distance (its fp32
  * evaluation is skipped) -- enough for every consumer that only gathers by index.
- * compute_norms == 0: xx [N] and ee [padded(K)] are inputs (from t5vq_row_sqnorms_f32 / t5vq_rmsnorm_sqnorms_f32).
- * compute_norms != 0: they are OUTPUTS: the pass that writes the fp16 images also writes the row norms (bit-identical
+ * compute_norms == 0: xx [N] and ee [padded(K)] are inputs (from t5vq_row_sqnorms_f32 / t5vq_rmsnorm_sqnorms_f32 /
+ * t5vq_ema_embed_f32's ee_out).
+ * compute_norms == 1: they are OUTPUTS: the pass that writes the fp16 images also writes the row norms (bit-identical
  * to t5vq_row_sqnorms_f32), which saves that launch and its read of x.
+ * compute_norms == 2: xx is an input, ee an output.  compute_norms == 3: xx is an output, ee an input.
  * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (fp16 images of x and w, bounds,
  * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan. */
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D);
@@ -249,17 +258,23 @@ int t5vq_rmsnorm_backward_f32(const float* grad_x, const float* hidden, const fl
  *
  * t5vq_vq_forward_f32 = vqvae/vqvae.py:103-128,147-152,160 (plain variant :24-64,71) plus the EMA statistics
  * of :133,:141 in one host call: row norms -> distance + argmin -> gather / straight-through / loss terms /
- * counts / embed_sum -> loss_sum[0] = sum of the loss terms.  `workspace` holds the per-call temporaries
- * (keys, |x|^2, |e|^2, loss partials): t5vq_forward_workspace_bytes(N, K) bytes, 16-byte aligned, caller-owned.
+ * counts / embed_sum (-> loss_sum[0] = sum of the loss terms, if loss_sum is given).  `workspace` holds the per-call
+ * temporaries (keys, |x|^2, |e|^2, loss terms): t5vq_forward_workspace_bytes(N, K) bytes, 16-byte aligned, caller-owned.
  * range, out_ste, out_q, out_diff, idx_out, counts, embed_sum, loss_sum are nullable as in
- * t5vq_dist_argmin_f32 / t5vq_gather_stats_f32.  xx_in (nullable): |x_i|^2 [N] already computed by the producer of
- * x (t5vq_rmsnorm_sqnorms_f32); the pass over x for the row norms is then skipped.  Whole-codebook form (code_offset 0, statistics for [0,K));
- * a code-sharded caller uses the fine-grained calls. */
+ * t5vq_dist_argmin_f32 / t5vq_gather_stats_f32.
+ * xx_in (nullable): |x_i|^2 [N] already computed by the producer of x (t5vq_rmsnorm_sqnorms_f32); the pass over x for
+ * the row norms is then skipped.  ee_in (nullable): |e_k|^2 [t5vq_padded_codes(K)], +inf padded, 16-byte aligned,
+ * e.g. the ee_out of the t5vq_vq_ema_finalize_f32 call that wrote this codebook; the pass over w is then skipped.
+ * loss_terms (nullable): caller buffer of t5vq_forward_loss_terms(N, embed_sum != NULL) floats that receives the
+ * unreduced loss terms; t5vq_vq_ema_finalize_f32 / t5vq_ema_cluster_f32 add them up themselves, so a single-GPU
+ * caller passes loss_terms and no loss_sum and saves the reduce launch.  Whole-codebook form (code_offset 0,
+ * statistics for [0,K)); a code-sharded caller uses the fine-grained calls. */
 int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K);
-int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
-                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
-                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                        t5vq_stream_t stream);
+int64_t t5vq_forward_loss_terms(int64_t N, int with_embed_sum);
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, const float* ee_in,
+                        int64_t N, int64_t K, int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes,
+                        float* out_ste, float* out_q, float* out_diff, int64_t* idx_out, float* counts,
+                        float* embed_sum, float* loss_terms, float* loss_sum, t5vq_stream_t stream);
 
 /* t5vq_vq_forward_f32 for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
  * that may not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it -- and
@@ -273,29 +288,32 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
  * overlap on one GPU (two streams, two host threads) race on it -- serialise them; calls on one stream are ordered
  * by the stream.  Nothing is carried from one call to the next (every temporary is rewritten before it is read). */
 #define T5VQ_NOALLOC_SCRATCH_BYTES (4 << 20)
-int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
-                                int64_t K, int64_t D, int loss_kind, float* out_ste, float* out_q, float* out_diff,
-                                int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                                t5vq_stream_t stream);
+int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, float* out_ste,
+                                float* out_q, float* out_diff, int64_t* idx_out, float* counts, float* embed_sum,
+                                float* loss_terms, float* loss_sum, t5vq_stream_t stream);
 
 /* The same forward (vqvae/vqvae.py:103-128,147-152,160 + :133,:141) with the filtered search of
  * t5vq_dist_argmin_filtered_f32 in place of the scan: identical indices and outputs, one host call.  Needs
  * D % 64 == 0, 64 <= D <= 4096.  workspace: t5vq_forward_filtered_workspace_bytes(N, K, D) bytes, 256-byte aligned.
- * n_overflow (nullable, device int32[1]): tokens the filter could not settle (decided by the scan kernel). */
+ * xx_in, ee_in, loss_terms as in t5vq_vq_forward_f32 (norms that are not given are written by the search's own
+ * first pass).  n_overflow (nullable, device int32[1]): tokens the filter could not settle (decided by the scan kernel). */
 int64_t t5vq_forward_filtered_workspace_bytes(int64_t N, int64_t K, int64_t D);
-int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
-                                 int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
-                                 float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                 const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, void* workspace,
+                                 int64_t workspace_bytes, float* out_ste, float* out_q, float* out_diff,
+                                 int64_t* idx_out, float* counts, float* embed_sum, float* loss_terms, float* loss_sum,
                                  int32_t* n_overflow, t5vq_stream_t stream);
 
 /* t5vq_vq_ema_finalize_f32 = vqvae/vqvae.py:131-144 (if update != 0) and the loss / perplexity scalars
  * (:148/:152,:157,:161-162): t5vq_ema_cluster_f32 (mode 1 or 0) followed by t5vq_ema_embed_f32.  A
- * token-sharded caller all-reduces counts / embed_sum / loss_sum between the two composite calls. */
+ * token-sharded caller all-reduces counts / embed_sum / loss_sum between the two composite calls.
+ * loss_sum / n_loss_terms as in t5vq_ema_cluster_f32, ee_out (nullable) as in t5vq_ema_embed_f32. */
 int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
-                             const float* embed_sum, const float* loss_sum, int64_t K, int64_t D, int64_t n_tokens,
-                             float loss_denom, float decay, float one_minus_decay, float epsilon, float k_epsilon,
-                             float commitment_cost, int plain_variant, int update, float* scalars,
-                             t5vq_stream_t stream);
+                             const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K, int64_t D,
+                             int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
+                             float k_epsilon, float commitment_cost, int plain_variant, int update, float* scalars,
+                             float* ee_out, t5vq_stream_t stream);
 
 #ifdef __cplusplus
 }

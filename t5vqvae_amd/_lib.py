@@ -1,7 +1,9 @@
-"""ctypes binding of the C-ABI library ``csrc/libt5vq.so`` (include/t5vq.h).
+"""Bindings of the two in-tree libraries: ``csrc/libt5vq.so`` (the C ABI of include/t5vq.h, through ctypes: the
+fine-grained entry points, the C-ABI tests) and ``csrc/libt5vq_torch.so`` (the PyTorch-ROCm extension over it:
+``torch.ops.t5vq.*``, what the nn.Modules call).
 
-There is no fallback: if the library is missing or fails to load, importing the ops raises.  The
-library is built in-tree by ``__graft_entry__.build()`` / ``make -C t5vqvae_amd/csrc``.
+There is no fallback: if a library is missing or fails to load, the ops raise.  Both are built in-tree by
+``__graft_entry__.build()`` / ``make -C t5vqvae_amd/csrc``.
 """
 from __future__ import annotations
 
@@ -30,12 +32,12 @@ SIGNATURES = {
     "t5vq_gather_stats_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, P, P, P, I64, I64, P, P, P, P, P]),
     "t5vq_order_by_code": (c_int, [P, I64, I64, P, P, P]),
     "t5vq_reduce_partials_f32": (c_int, [P, I64, P, P]),
-    "t5vq_ema_cluster_f32": (c_int, [P, P, P, I64, I64, c_float, c_float, c_float, c_float, c_float, c_float,
+    "t5vq_ema_cluster_f32": (c_int, [P, P, P, I64, I64, I64, c_float, c_float, c_float, c_float, c_float, c_float,
                                      c_int, c_int, P, P]),
-    "t5vq_ema_embed_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P]),
+    "t5vq_ema_embed_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P, P]),
     "t5vq_max_norm_f32": (c_int, [P, I64, P, P]),
     "t5vq_embed_sum_fixed_f32": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P]),
-    "t5vq_ema_embed_fixed_f32": (c_int, [P, P, P, P, P, I64, I64, c_float, c_float, P]),
+    "t5vq_ema_embed_fixed_f32": (c_int, [P, P, P, P, P, I64, I64, c_float, c_float, P, P]),
     "t5vq_ste_backward_f32": (c_int, [P, P, P, c_float, I64, P, P]),
     "t5vq_scatter_rows_f32": (c_int, [P, P, P, c_float, I64, I64, I64, P, P]),
     "t5vq_cosine_backward_f32": (c_int, [P, P, P, P, c_float, c_float, I64, I64, P, P, P]),
@@ -48,15 +50,20 @@ SIGNATURES = {
     "t5vq_rmsnorm_backward_blocks": (I64, [I64]),
     "t5vq_rmsnorm_backward_f32": (c_int, [P, P, P, P, c_float, P, I64, I64, P, P, P, P]),
     "t5vq_forward_workspace_bytes": (I64, [I64, I64]),
-    "t5vq_vq_forward_f32": (c_int, [P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P]),
-    "t5vq_vq_forward_noalloc_f32": (c_int, [P, P, P, P, I64, I64, I64, c_int, P, P, P, P, P, P, P, P]),
+    "t5vq_forward_loss_terms": (I64, [I64, c_int]),
+    "t5vq_vq_forward_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P]),
+    "t5vq_vq_forward_noalloc_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, P, P, P, P, P, P, P, P]),
     "t5vq_forward_filtered_workspace_bytes": (I64, [I64, I64, I64]),
-    "t5vq_vq_forward_filtered_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P]),
-    "t5vq_vq_ema_finalize_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, c_float, c_float, c_float, c_float,
-                                         c_float, c_float, c_int, c_int, P, P]),
+    "t5vq_vq_forward_filtered_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P,
+                                             P]),
+    "t5vq_vq_ema_finalize_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, I64, c_float, c_float, c_float, c_float,
+                                         c_float, c_float, c_int, c_int, P, P, P]),
 }
 
+TORCH_LIB_PATH = os.environ.get("T5VQ_TORCH_LIB") or os.path.join(_HERE, "csrc", "libt5vq_torch.so")
+
 _lib = None
+_torch_ops = None
 
 
 class T5VQError(RuntimeError):
@@ -79,6 +86,22 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def load_torch_ops():
+    """``torch.ops.t5vq`` (once): the TORCH_LIBRARY extension csrc/t5vq_torch.cpp.  Raises if it is missing."""
+    global _torch_ops
+    if _torch_ops is not None:
+        return _torch_ops
+    import torch
+    load()                                   # libt5vq.so first: the extension links against it
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise T5VQError(
+            f"{TORCH_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C t5vqvae_amd/csrc`.  t5vqvae_amd has no CPU fallback.")
+    torch.ops.load_library(TORCH_LIB_PATH)
+    _torch_ops = torch.ops.t5vq
+    return _torch_ops
 
 
 def check(status: int, what: str):

@@ -15,6 +15,7 @@
 // smallest lower bounds; collect_kernel forms T_i and filters the kept pairs.  A token with more than CAND_MAX
 // candidates, or with a scanner that may have dropped one, is decided by the fp32 scan kernel run on those tokens only.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 
@@ -55,7 +56,8 @@ __device__ __forceinline__ long long pack_key(float d, int idx) {
 // [2^14, 2^15): the scaling is exact, rows of any magnitude (dead codes reach 1e6) fit fp16's range, and elements
 // down to 2^-28 of the row maximum keep 11 significant bits.  inv[row] = the inverse factor (a power of two).
 // One wave per row; se[k] = sqrt(ee[k]) for the error bound.
-template <int NCH, bool NORMS>
+// norm_x / norm_w: this pass also writes |x|^2 / |e|^2 (otherwise they are inputs).
+template <int NCH>
 __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restrict__ x, long long n_x,
                                                           _Float16* __restrict__ xh, float* __restrict__ x_inv,
                                                           const float* __restrict__ w, long long n_w,
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           float* __restrict__ xx, float* __restrict__ ee,
                                                           long long kpad, float* __restrict__ se, int D,
                                                           int* __restrict__ n_list, int* __restrict__ tshare,
-                                                          unsigned row_blocks, T5vqZeroArgs zero) {
+                                                          unsigned row_blocks, T5vqZeroArgs zero, int norm_x,
+                                                          int norm_w) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= row_blocks) {   // the tail of the grid zeroes the caller's buffers: 4096 words per workgroup
         long long i = (static_cast<long long>(blockIdx.x - row_blocks) * 256 + threadIdx.x) * 16;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         if (row >= kpad) return;
         if (row >= n_w) {   // padding of the |e|^2 buffers: +inf, so padded codes can never be candidates
             if (lane == 0) {
-                if (NORMS) ee[row] = __int_as_float(0x7F800000);
+                if (norm_w) ee[row] = __int_as_float(0x7F800000);
                 se[row] = __int_as_float(0x7F800000);
                 w_inv[row] = 1.0f;
             }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     }
     float sq = 0.f;
-    if (NORMS) {   // the squared norm, in row_sqnorms_kernel's lane layout and order (bit-identical to it)
+    if (is_w ? norm_w : norm_x) {   // the squared norm, in row_sqnorms_kernel's lane layout and order (bit-identical to it)
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             sq = fmaf(v[j].x, v[j].x, sq);
@@ -708,7 +711,7 @@ int64_t plan_filter_splits(int64_t N, int64_t K) {
     }
     return 1;
 }
-bool attr_done[64] = {};
+std::atomic<bool> attr_done[64];   // idempotent set-up, may race between host threads
 
 }  // namespace
 
@@ -734,6 +737,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
                                        int exact_keys, void* workspace, int64_t workspace_bytes, int64_t* keys,
                                        int32_t* n_overflow, T5vqZeroArgs zero, hipStream_t stream) {
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
+    T5VQ_I_REQUIRE(compute_norms >= 0 && compute_norms <= 3, "compute_norms must be 0..3");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
     T5VQ_I_REQUIRE(D >= 64 && D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, 64 <= D <= 4096");
     T5VQ_I_REQUIRE(code_offset >= 0 && code_offset + K < (1LL << 31), "code_offset out of range");
@@ -746,12 +750,12 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     T5VQ_I_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_filter_workspace_bytes(N, K, D)");
     int dev = 0;
     T5VQ_I_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         T5VQ_I_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_f16_kernel<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     char* base = static_cast<char*>(workspace);
     _Float16* xb = reinterpret_cast<_Float16*>(base + ws.xb);
@@ -781,15 +785,13 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
         }
         const dim3 pgrid(row_blocks + static_cast<unsigned>(zero_blocks));
         const int nch = static_cast<int>((D + 255) / 256);
+        // compute_norms: 0 = xx and ee are inputs, 1 = both outputs, 2 = xx input / ee output, 3 = xx output / ee input
+        const int norm_x = (compute_norms == 1 || compute_norms == 3) ? 1 : 0;
+        const int norm_w = (compute_norms == 1 || compute_norms == 2) ? 1 : 0;
 #define T5VQ_PREP(NCH_)                                                                                          \
-    if (compute_norms)                                                                                                 \
-        hipLaunchKernelGGL((filter_prep_kernel<NCH_, true>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),    \
-                           xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list, tshare, row_blocks, zero);                                                               \
-    else                                                                                                               \
-        hipLaunchKernelGGL((filter_prep_kernel<NCH_, false>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N),   \
-                           xb, x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se, \
-                           static_cast<int>(D), n_list, tshare, row_blocks, zero)
+    hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
+                       x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se,  \
+                       static_cast<int>(D), n_list, tshare, row_blocks, zero, norm_x, norm_w)
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }

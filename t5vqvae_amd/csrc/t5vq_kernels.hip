@@ -80,6 +80,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// |row|^2 by one wave: lane l takes float4 #l, #l+64, ... in a k-ordered fma chain, then the xor butterfly.  THE
+// definition of a row norm in this library: every kernel that produces |x|^2 or |e|^2 (row_sqnorms_kernel, the
+// self-contained distance kernel's prologue, ema_embed_kernel, filter_prep_kernel, rmsnorm_sqnorms_kernel) uses this
+// lane layout and order, so their results are bit-identical and interchangeable.
+__device__ __forceinline__ float sq4(const f32x4 v, float s) {
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+    return s;
+}
+__device__ __forceinline__ float row_sqnorm_wave(const float* __restrict__ row, int D, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(row);
+    float s = 0.f;
+    for (int i = lane; i < (D >> 2); i += 64) s = sq4(p[i], s);
+    return wave_sum(s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K0: row squared norms (one wave per row, two matrices per launch)
 // ------------------------------------------------------------------------------------------------
@@ -90,6 +108,8 @@ struct PrepArgs {
     long long n_a;
     float* zero_b;       // embed_sum
     long long n_b;
+    float* zero_c;       // the counting sort's cursors (int32 words)
+    long long n_c;
     long long* keys;     // filled with KEY_NONE (code splits merge into it with atomicMin)
     long long n_keys;
     int blocks;          // workgroups appended to the grid for this
@@ -120,6 +140,7 @@ __global__ __launch_bounds__(256) void row_sqnorms_kernel(const float* __restric
         const long long gstride = static_cast<long long>(prep.blocks) * 256;
         zero_floats(prep.zero_a, prep.n_a, gtid, gstride);
         zero_floats(prep.zero_b, prep.n_b, gtid, gstride);
+        zero_floats(prep.zero_c, prep.n_c, gtid, gstride);
         if (prep.keys)
             for (long long i = gtid; i < prep.n_keys; i += gstride) prep.keys[i] = KEY_NONE;
         return;
@@ -139,16 +160,7 @@ __global__ __launch_bounds__(256) void row_sqnorms_kernel(const float* __restric
         if (lane == 0) dst[row] = __int_as_float(0x7F800000);  // +inf: padded codes never win the argmin
         return;
     }
-    const f32x4* p = reinterpret_cast<const f32x4*>(src + row * D);
-    float s = 0.f;
-    for (int i = lane; i < (D >> 2); i += 64) {
-        f32x4 v = p[i];
-        s = fmaf(v.x, v.x, s);
-        s = fmaf(v.y, v.y, s);
-        s = fmaf(v.z, v.z, s);
-        s = fmaf(v.w, v.w, s);
-    }
-    s = wave_sum(s);
+    const float s = row_sqnorm_wave(src + row * D, D, lane);
     if (lane == 0) dst[row] = s;
 }
 
@@ -1077,9 +1089,9 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
     }
 }
 
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ p, long long n,
-                                                              float* __restrict__ out) {
-    __shared__ double s[16];
+// Sum of n loss terms in a FIXED order (four strided fp64 accumulators per thread, wave butterflies, wave totals in
+// wave order): the same value whichever kernel calls it.  1024 threads; the total is valid in thread 0.
+__device__ __forceinline__ double sum_terms_1024(const float* __restrict__ p, long long n, double* s /*[16]*/) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent loads in flight; fixed order for a given n
     long long i = threadIdx.x;
     for (; i + 3 * 1024 < n; i += 4 * 1024) {
@@ -1090,14 +1102,21 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
         a3 += static_cast<double>(v3);
     }
     for (; i < n; i += 1024) a0 += static_cast<double>(p[i]);
-    double acc = wave_sum_d((a0 + a1) + (a2 + a3));
+    const double acc = wave_sum_d((a0 + a1) + (a2 + a3));
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
+    double t = 0.0;
+    if (threadIdx.x == 0)
         for (int k = 0; k < 16; ++k) t += s[k];
-        out[0] = static_cast<float>(t);
-    }
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ p, long long n,
+                                                              float* __restrict__ out) {
+    __shared__ double s[16];
+    const double t = sum_terms_1024(p, n, s);
+    if (threadIdx.x == 0) out[0] = static_cast<float>(t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1116,23 +1135,40 @@ __device__ double block_sum_d(double v, double* s) {
 // mode 0: scalars only (eval).  mode 1: fused update.  mode 2: phase 1 of a code-sharded update
 // (cs <- cs*decay + omd*counts; scalars[1] = local sum p log(p+1e-10), scalars[2] = local sum cs).
 // mode 3: phase 2 (reads the all-reduced scalars[1], scalars[2]; normalises cs; writes perplexity).
+// loss_terms[0 .. n_terms) are summed here (n_terms == 1: a ready sum) -- the forward leaves its loss terms
+// unreduced, which saves the reduce launch.  VEC: cs and counts are 16-byte aligned and K % 4 == 0, so each thread
+// walks float4s (K = 10000: 3 dependent round trips instead of 10).
+template <bool VEC>
 __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ cs, const float* __restrict__ counts,
-                                                           const float* __restrict__ loss_sum, int K, float n_tokens,
-                                                           float loss_denom, float decay, float omd, float eps,
-                                                           float k_eps, float cc, int plain_variant, int mode,
-                                                           float* __restrict__ scalars) {
+                                                           const float* __restrict__ loss_terms, long long n_terms,
+                                                           int K, float n_tokens, float loss_denom, float decay,
+                                                           float omd, float eps, float k_eps, float cc,
+                                                           int plain_variant, int mode, float* __restrict__ scalars) {
     __shared__ double s[16];
     double ent = 0.0, nsum = 0.0;
     float n = 0.f;
+    const bool upd = mode != 0 && cs;
+    auto one = [&](float c, float old) {
+        const float p = __fdiv_rn(c, n_tokens);
+        ent += static_cast<double>(__fmul_rn(p, logf(__fadd_rn(p, 1e-10f))));
+        const float v = __fadd_rn(__fmul_rn(old, decay), __fmul_rn(omd, c));
+        if (upd) nsum += static_cast<double>(v);
+        return v;
+    };
     if (mode != 3) {
-        for (int k = threadIdx.x; k < K; k += blockDim.x) {
-            const float c = counts[k];
-            const float p = __fdiv_rn(c, n_tokens);
-            ent += static_cast<double>(__fmul_rn(p, logf(__fadd_rn(p, 1e-10f))));
-            if (mode != 0 && cs) {
-                const float v = __fadd_rn(__fmul_rn(cs[k], decay), __fmul_rn(omd, c));
-                cs[k] = v;
-                nsum += static_cast<double>(v);
+        if (VEC) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            for (int k4 = threadIdx.x; k4 < (K >> 2); k4 += blockDim.x) {
+                const f32x4 c = reinterpret_cast<const f32x4*>(counts)[k4];
+                const f32x4 o = upd ? reinterpret_cast<const f32x4*>(cs)[k4] : zero4;
+                f32x4 v;
+                v.x = one(c.x, o.x), v.y = one(c.y, o.y), v.z = one(c.z, o.z), v.w = one(c.w, o.w);
+                if (upd) reinterpret_cast<f32x4*>(cs)[k4] = v;
+            }
+        } else {
+            for (int k = threadIdx.x; k < K; k += blockDim.x) {
+                const float v = one(counts[k], upd ? cs[k] : 0.f);
+                if (upd) cs[k] = v;
             }
         }
         ent = block_sum_d(ent, s);
@@ -1144,11 +1180,24 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
     }
     if ((mode == 1 || mode == 3) && cs) {
         const float den = __fadd_rn(n, k_eps);
-        for (int k = threadIdx.x; k < K; k += blockDim.x)  // mode 1: each thread re-reads only what it wrote
-            cs[k] = __fmul_rn(__fdiv_rn(__fadd_rn(cs[k], eps), den), n);
+        if (VEC) {
+            for (int k4 = threadIdx.x; k4 < (K >> 2); k4 += blockDim.x) {  // each thread re-reads only what it wrote
+                f32x4 v = reinterpret_cast<f32x4*>(cs)[k4];
+                v.x = __fmul_rn(__fdiv_rn(__fadd_rn(v.x, eps), den), n);
+                v.y = __fmul_rn(__fdiv_rn(__fadd_rn(v.y, eps), den), n);
+                v.z = __fmul_rn(__fdiv_rn(__fadd_rn(v.z, eps), den), n);
+                v.w = __fmul_rn(__fdiv_rn(__fadd_rn(v.w, eps), den), n);
+                reinterpret_cast<f32x4*>(cs)[k4] = v;
+            }
+        } else {
+            for (int k = threadIdx.x; k < K; k += blockDim.x)  // mode 1: each thread re-reads only what it wrote
+                cs[k] = __fmul_rn(__fdiv_rn(__fadd_rn(cs[k], eps), den), n);
+        }
     }
+    double lsum = 0.0;
+    if (loss_terms) lsum = n_terms == 1 ? static_cast<double>(loss_terms[0]) : sum_terms_1024(loss_terms, n_terms, s);
     if (threadIdx.x == 0) {
-        const float m = loss_sum ? __fdiv_rn(loss_sum[0], loss_denom) : 0.f;
+        const float m = loss_terms ? __fdiv_rn(static_cast<float>(lsum), loss_denom) : 0.f;
         const float cm = __fmul_rn(cc, m);
         scalars[0] = plain_variant ? __fadd_rn(m, cm) : cm;
         scalars[1] = mode == 2 ? static_cast<float>(ent) : expf(static_cast<float>(-ent));
@@ -1158,9 +1207,13 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
 }
 
 // K4b: codebook EMA, one wave per code row
+// ee_out (nullable): |e_row|^2 of the row just written, accumulated in row_sqnorm_wave's lane layout and order from
+// the values in registers -- bit-identical to t5vq_row_sqnorms_f32 run on the new codebook, so the next call need not
+// read the codebook for its norms (vqvae/vqvae.py:107 recomputes them every call).
 __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
                                                         const float* __restrict__ dw, const float* __restrict__ cs,
-                                                        int K, int D, float decay, float omd) {
+                                                        int K, int D, float decay, float omd,
+                                                        float* __restrict__ ee_out) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= K) return;
@@ -1168,6 +1221,7 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
     f32x4* e = reinterpret_cast<f32x4*>(ema_w + row * D);
     f32x4* o = reinterpret_cast<f32x4*>(w + row * D);
     const f32x4* s = reinterpret_cast<const f32x4*>(dw + row * D);
+    float sq = 0.f;
     for (int i = lane; i < (D >> 2); i += 64) {
         const f32x4 a = e[i], b = s[i];
         f32x4 v, q;
@@ -1181,6 +1235,11 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
         q.w = __fdiv_rn(v.w, c);
         e[i] = v;
         o[i] = q;
+        sq = sq4(q, sq);
+    }
+    if (ee_out) {
+        sq = wave_sum(sq);
+        if (lane == 0) ee_out[row] = sq;
     }
 }
 
@@ -1415,17 +1474,29 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
                                                               const long long* __restrict__ dw,
                                                               const int* __restrict__ max_xx_bits,
                                                               const float* __restrict__ cs, int K, int D, float decay,
-                                                              float omd) {
+                                                              float omd, float* __restrict__ ee_out) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= K) return;
     const double inv = ldexp(1.0, -fixed_shift(*max_xx_bits));
     const float c = cs[row];
-    for (int i = lane; i < D; i += 64) {
-        const float b = static_cast<float>(static_cast<double>(dw[row * D + i]) * inv);
-        const float v = __fadd_rn(__fmul_rn(ema_w[row * D + i], decay), __fmul_rn(omd, b));
-        ema_w[row * D + i] = v;
-        w[row * D + i] = __fdiv_rn(v, c);
+    float sq = 0.f;
+    for (int i4 = lane; i4 < (D >> 2); i4 += 64) {   // float4 #i4 per lane: row_sqnorm_wave's layout
+        f32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = row * D + 4 * i4 + e;
+            const float b = static_cast<float>(static_cast<double>(dw[i]) * inv);
+            const float v = __fadd_rn(__fmul_rn(ema_w[i], decay), __fmul_rn(omd, b));
+            ema_w[i] = v;
+            q[e] = __fdiv_rn(v, c);
+            w[i] = q[e];
+        }
+        sq = sq4(q, sq);
+    }
+    if (ee_out) {
+        sq = wave_sum(sq);
+        if (lane == 0) ee_out[row] = sq;
     }
 }
 
@@ -1790,7 +1861,7 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
 // ================================================================================================
 extern "C" {
 
-int t5vq_version(void) { return 100; }
+int t5vq_version(void) { return 200; }
 int t5vq_set_tuning(int variant) {
     g_depth2 = variant >= 100000 ? 0 : 1;   // +100000: single staging register set
     variant %= 100000;
@@ -1810,9 +1881,9 @@ static int launch_row_sqnorms(const float* x, int64_t N, float* xx, const float*
     T5VQ_REQUIRE(K == 0 || (w && ee && aligned16(w)), "w/ee null or w not 16-byte aligned");
     const int64_t kpad = t5vq_padded_codes(K);
     const int64_t bx = (N + 3) / 4, bw = (kpad + 3) / 4;
-    const int64_t prep_elems = (prep.n_a + prep.n_b) / 4 + prep.n_keys;
+    const int64_t prep_elems = (prep.n_a + prep.n_b + prep.n_c) / 4 + prep.n_keys;
     prep.blocks = 0;
-    if (prep.zero_a || prep.zero_b || prep.keys) {
+    if (prep.zero_a || prep.zero_b || prep.zero_c || prep.keys) {
         int64_t pb = (prep_elems + 1023) / 1024;  // ~4 stores per thread
         prep.blocks = static_cast<int>(pb < 1 ? 1 : (pb > 2048 ? 2048 : pb));
     }
@@ -1950,29 +2021,39 @@ int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, 
     return T5VQ_OK;
 }
 
-int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t K,
-                         int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
-                         float k_epsilon, float commitment_cost, int plain_variant, int mode, float* scalars,
-                         t5vq_stream_t stream) {
+int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* loss_sum, int64_t n_loss_terms,
+                         int64_t K, int64_t n_tokens, float loss_denom, float decay, float one_minus_decay,
+                         float epsilon, float k_epsilon, float commitment_cost, int plain_variant, int mode,
+                         float* scalars, t5vq_stream_t stream) {
     T5VQ_REQUIRE(scalars && (counts || mode == 3), "counts/scalars null");
     T5VQ_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0..3");
     T5VQ_REQUIRE(mode != 1 || cluster_size, "cluster_size null with mode 1");
     T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && n_tokens > 0, "K, n_tokens out of range");
-    hipLaunchKernelGGL(ema_cluster_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), cluster_size,
-                       counts, loss_sum, static_cast<int>(K), static_cast<float>(n_tokens), loss_denom, decay,
-                       one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, mode, scalars);
+    T5VQ_REQUIRE(!loss_sum || n_loss_terms >= 1, "n_loss_terms must be at least 1 when loss_sum is given");
+    const bool vec = K % 4 == 0 && (!counts || aligned16(counts)) && (!cluster_size || aligned16(cluster_size));
+#define T5VQ_CL(VEC_)                                                                                              \
+    hipLaunchKernelGGL((ema_cluster_kernel<VEC_>), dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),       \
+                       cluster_size, counts, loss_sum, static_cast<long long>(n_loss_terms), static_cast<int>(K),  \
+                       static_cast<float>(n_tokens), loss_denom, decay, one_minus_decay, epsilon, k_epsilon,      \
+                       commitment_cost, plain_variant, mode, scalars)
+    if (vec) {
+        T5VQ_CL(true);
+    } else {
+        T5VQ_CL(false);
+    }
+#undef T5VQ_CL
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }
 
 int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
-                       int64_t D, float decay, float one_minus_decay, t5vq_stream_t stream) {
+                       int64_t D, float decay, float one_minus_decay, float* ee_out, t5vq_stream_t stream) {
     T5VQ_REQUIRE(ema_w && w && embed_sum && cluster_size, "null pointer");
     T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0 && D % 4 == 0, "K, D out of range");
     T5VQ_REQUIRE(aligned16(ema_w) && aligned16(w) && aligned16(embed_sum), "buffers must be 16-byte aligned");
     hipLaunchKernelGGL(ema_embed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),
-                       static_cast<int>(D), decay, one_minus_decay);
+                       static_cast<int>(D), decay, one_minus_decay, ee_out);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }
@@ -2030,12 +2111,13 @@ int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t*
 
 int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
                              const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
-                             t5vq_stream_t stream) {
+                             float* ee_out, t5vq_stream_t stream) {
     T5VQ_REQUIRE(ema_w && w && embed_sum && max_xx_bits && cluster_size, "null pointer");
-    T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0, "K, D out of range");
+    T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0 && D % 4 == 0, "K, D out of range");
     hipLaunchKernelGGL(ema_embed_fixed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ema_w, w, reinterpret_cast<const long long*>(embed_sum),
-                       max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay);
+                       max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay,
+                       ee_out);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }
@@ -2231,17 +2313,24 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
 
 // Launches: [row norms + buffer preparation] -> [distance + argmin] -> ([order tokens by code: 3 small launches],
 // training with N >= 32768) -> [gather + statistics] -> [loss sum].
-static int vq_forward_impl(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
-                           int64_t K, int64_t D, int loss_kind, void* workspace, float* out_ste, float* out_q,
-                           float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                           hipStream_t stream) {
+int64_t t5vq_forward_loss_terms(int64_t N, int with_embed_sum) {
+    if (N <= 0) return 0;
+    return (with_embed_sum && N >= GS_SMALL_N) ? N : t5vq_gather_blocks(N);
+}
+
+static int vq_forward_impl(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                           const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, void* workspace,
+                           float* out_ste, float* out_q, float* out_diff, int64_t* idx_out, float* counts,
+                           float* embed_sum, float* loss_terms, float* loss_sum, hipStream_t stream) {
     const FwdWorkspace ws(N, K);
     T5VQ_REQUIRE(x && w, "null input");
+    T5VQ_REQUIRE(!ee_in || aligned16(ee_in), "ee_in must be 16-byte aligned");
     char* base = static_cast<char*>(workspace);
     int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
     const float* xx = xx_in ? xx_in : reinterpret_cast<float*>(base + ws.xx);
-    float* ee = reinterpret_cast<float*>(base + ws.ee);
-    float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
+    const float* ee = ee_in ? ee_in : reinterpret_cast<float*>(base + ws.ee);
+    float* partial = loss_terms ? loss_terms : (loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr);
+    const bool order = embed_sum && N >= GS_SMALL_N;   // statistics wanted, enough tokens for the ordering to pay
     PrepArgs prep{};
     prep.zero_a = counts;
     prep.n_a = counts ? K : 0;
@@ -2249,18 +2338,24 @@ static int vq_forward_impl(const float* x, const float* w, const int64_t* range,
     prep.n_b = embed_sum ? K * D : 0;
     prep.keys = reinterpret_cast<long long*>(keys);
     prep.n_keys = N;
-    // |x|^2 may come from the producer of x (t5vq_rmsnorm_sqnorms_f32): then only |e|^2 is computed here
-    int rc = xx_in ? launch_row_sqnorms(nullptr, 0, nullptr, w, K, ee, D, prep, stream)
-                   : launch_row_sqnorms(x, N, reinterpret_cast<float*>(base + ws.xx), w, K, ee, D, prep, stream);
+    if (order) {   // the counting sort's cursors are zeroed by the same launch (a memset launch less)
+        prep.zero_c = reinterpret_cast<float*>(base + ws.work);
+        prep.n_c = K + 2;
+    }
+    // |x|^2 may come from the producer of x (t5vq_rmsnorm_sqnorms_f32) and |e|^2 from the finalize call that wrote
+    // the codebook (t5vq_vq_ema_finalize_f32's ee_out): whatever is given is not recomputed here
+    int rc = launch_row_sqnorms(xx_in ? nullptr : x, xx_in ? 0 : N, xx_in ? nullptr : reinterpret_cast<float*>(base + ws.xx),
+                                ee_in ? nullptr : w, ee_in ? 0 : K, ee_in ? nullptr : reinterpret_cast<float*>(base + ws.ee),
+                                D, prep, stream);
     if (rc != T5VQ_OK) return rc;
     DistOpts opts;
     opts.keys_prefilled = true;
     rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream, opts);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
-    if (embed_sum && N >= GS_SMALL_N) {   // statistics wanted, enough tokens for the ordering to pay for itself
+    if (order) {
         int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
-        rc = t5vq_order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        rc = order_by_code(keys, N, K, p, reinterpret_cast<int32_t*>(base + ws.work), true, stream);
         if (rc != T5VQ_OK) return rc;
         perm = p;
     }
@@ -2270,15 +2365,15 @@ static int vq_forward_impl(const float* x, const float* w, const int64_t* range,
     return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
 }
 
-int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N, int64_t K,
-                        int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
-                        float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                        t5vq_stream_t stream_) {
+int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, const float* ee_in,
+                        int64_t N, int64_t K, int64_t D, int loss_kind, void* workspace, int64_t workspace_bytes,
+                        float* out_ste, float* out_q, float* out_diff, int64_t* idx_out, float* counts,
+                        float* embed_sum, float* loss_terms, float* loss_sum, t5vq_stream_t stream_) {
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
     T5VQ_REQUIRE(workspace && aligned16(workspace), "workspace null or not 16-byte aligned");
     T5VQ_REQUIRE(workspace_bytes >= FwdWorkspace(N, K).total, "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
-    return vq_forward_impl(x, w, range, xx_in, N, K, D, loss_kind, workspace, out_ste, out_q, out_diff, idx_out, counts,
-                           embed_sum, loss_sum, static_cast<hipStream_t>(stream_));
+    return vq_forward_impl(x, w, range, xx_in, ee_in, N, K, D, loss_kind, workspace, out_ste, out_q, out_diff, idx_out,
+                           counts, embed_sum, loss_terms, loss_sum, static_cast<hipStream_t>(stream_));
 }
 
 // ---- The forward for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
@@ -2309,10 +2404,10 @@ int scratch_for_current_device(void** out) {
 }
 }  // namespace
 
-int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in, int64_t N,
-                                int64_t K, int64_t D, int loss_kind, float* out_ste, float* out_q, float* out_diff,
-                                int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
-                                t5vq_stream_t stream_) {
+int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, float* out_ste,
+                                float* out_q, float* out_diff, int64_t* idx_out, float* counts, float* embed_sum,
+                                float* loss_terms, float* loss_sum, t5vq_stream_t stream_) {
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
     T5VQ_REQUIRE(N < (1LL << 31) && K < (1LL << 31), "N or K too large");
     if (FwdWorkspace(N, K).total > static_cast<int64_t>(T5VQ_NOALLOC_SCRATCH_BYTES)) {
@@ -2327,8 +2422,8 @@ int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* r
     if (rc != T5VQ_OK) return rc;
     // every temporary is (re)written before it is read: keys are filled with 'none' and the statistics zeroed by the
     // first launch, the sort cursors by a memset on `stream`; nothing of the previous call's contents is used
-    return vq_forward_impl(x, w, range, xx_in, N, K, D, loss_kind, ptr, out_ste, out_q, out_diff, idx_out, counts,
-                           embed_sum, loss_sum, static_cast<hipStream_t>(stream_));
+    return vq_forward_impl(x, w, range, xx_in, ee_in, N, K, D, loss_kind, ptr, out_ste, out_q, out_diff, idx_out,
+                           counts, embed_sum, loss_terms, loss_sum, static_cast<hipStream_t>(stream_));
 }
 
 // The same forward with the filtered search (t5vq_filter.hip) in place of the scan: [fp16 images + row norms] ->
@@ -2339,9 +2434,10 @@ int64_t t5vq_forward_filtered_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     return FwdWorkspace(N, K).total + t5vq_filter_workspace_bytes(N, K, D);
 }
 
-int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, int64_t N, int64_t K, int64_t D,
-                                 int loss_kind, void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
-                                 float* out_diff, int64_t* idx_out, float* counts, float* embed_sum, float* loss_sum,
+int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                 const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, void* workspace,
+                                 int64_t workspace_bytes, float* out_ste, float* out_q, float* out_diff,
+                                 int64_t* idx_out, float* counts, float* embed_sum, float* loss_terms, float* loss_sum,
                                  int32_t* n_overflow, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
@@ -2353,9 +2449,11 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
     T5VQ_REQUIRE(x && w, "null input");
     char* base = static_cast<char*>(workspace);
     int64_t* keys = reinterpret_cast<int64_t*>(base + ws.keys);
-    float* xx = reinterpret_cast<float*>(base + ws.xx);
-    float* ee = reinterpret_cast<float*>(base + ws.ee);
-    float* partial = loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr;
+    // given norms are used as they are (they are inputs of the search then); the others are written by its first pass
+    float* xx = xx_in ? const_cast<float*>(xx_in) : reinterpret_cast<float*>(base + ws.xx);
+    float* ee = ee_in ? const_cast<float*>(ee_in) : reinterpret_cast<float*>(base + ws.ee);
+    const int compute_norms = xx_in ? (ee_in ? 0 : 2) : (ee_in ? 3 : 1);
+    float* partial = loss_terms ? loss_terms : (loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr);
     // index-only keys: the distance word of a token with a single candidate is an upper bound, not the distance
     // the search's first kernel also zeroes the statistics and the sort counters (three memset launches less)
     const bool order = embed_sum && N >= GS_SMALL_N;
@@ -2371,8 +2469,8 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
         zero.p[2] = base + ws.work;
         zero.n[2] = K + 2;
     }
-    int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, 1, range, N, K, D, 0, 0, base + ws.total, filter_bytes,
-                                                keys, n_overflow, zero, stream);
+    int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, N, K, D, 0, 0, base + ws.total,
+                                                filter_bytes, keys, n_overflow, zero, stream);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
     if (order) {
@@ -2388,16 +2486,16 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
 }
 
 int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
-                             const float* embed_sum, const float* loss_sum, int64_t K, int64_t D, int64_t n_tokens,
-                             float loss_denom, float decay, float one_minus_decay, float epsilon, float k_epsilon,
-                             float commitment_cost, int plain_variant, int update, float* scalars,
-                             t5vq_stream_t stream) {
+                             const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K, int64_t D,
+                             int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
+                             float k_epsilon, float commitment_cost, int plain_variant, int update, float* scalars,
+                             float* ee_out, t5vq_stream_t stream) {
     T5VQ_REQUIRE(!update || (cluster_size && ema_w && w && embed_sum), "update needs cluster_size, ema_w, w, embed_sum");
-    int rc = t5vq_ema_cluster_f32(update ? cluster_size : nullptr, counts, loss_sum, K, n_tokens, loss_denom, decay,
-                                  one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
-                                  update ? 1 : 0, scalars, stream);
+    int rc = t5vq_ema_cluster_f32(update ? cluster_size : nullptr, counts, loss_sum, n_loss_terms, K, n_tokens,
+                                  loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
+                                  plain_variant, update ? 1 : 0, scalars, stream);
     if (rc != T5VQ_OK || !update) return rc;
-    return t5vq_ema_embed_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, stream);
+    return t5vq_ema_embed_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, ee_out, stream);
 }
 
 }  // extern "C"

@@ -1,6 +1,12 @@
-"""Tensor-level wrappers of the C ABI (include/t5vq.h): argument checks, output/workspace allocation
-(torch's caching allocator: plumbing), launch on torch's current HIP stream.  No arithmetic happens
-here; every function enqueues kernels and returns without synchronising.
+"""Tensor-level wrappers of the kernels: argument checks, output/workspace allocation (torch's caching allocator:
+plumbing), launch on torch's current HIP stream.  No arithmetic happens here; every function enqueues kernels and
+returns without synchronising.
+
+Two routes to the same C ABI (include/t5vq.h):
+* ``fused_step / fused_forward / fused_finalize`` and the backward / helper ops go through the PyTorch-ROCm extension
+  ``torch.ops.t5vq`` (csrc/t5vq_torch.cpp) -- what the nn.Modules call: one op per module call;
+* the fine-grained functions bind the C ABI directly with ctypes (code-sharded codebooks, role-bucketed search, the
+  C-ABI tests).
 """
 from __future__ import annotations
 
@@ -34,6 +40,11 @@ def _need(t: torch.Tensor, name: str, dtype=torch.float32, ndim: Optional[int] =
     if ndim is not None and t.dim() != ndim:
         raise RuntimeError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
     return t
+
+
+def require_device(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device (got {t.device}); t5vqvae_amd has no CPU path")
 
 
 def padded_codes(k: int) -> int:
@@ -92,11 +103,13 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
 
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True,
-                         ranges=None, code_offset: int = 0):
+                         ranges=None, code_offset: int = 0, return_norms: bool = False):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
-    (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None: the row norms are computed by the call's own first pass
-    (no separate ``row_sqnorms``).  ``exact_keys=False``: only the index word is guaranteed (cheaper).
-    Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``."""
+    (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None (either or both): that norm is computed by the call's own
+    first pass (no separate ``row_sqnorms``); a given norm is only read.  ``exact_keys=False``: only the index word is
+    guaranteed (cheaper).
+    Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``; ``return_norms`` appends (xx, ee) -- the
+    norms the search used, whether given or computed."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
@@ -109,10 +122,13 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
         _need(ranges, "ranges", torch.int64, 2)
         if tuple(ranges.shape) != (n, 2):
             raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
-    compute = xx is None or ee is None
-    if compute:
-        if xx is None:
-            xx = torch.empty(n, dtype=torch.float32, device=x.device)
+    # compute_norms of the C ABI: 0 both given, 1 both computed (outputs), 2 xx given / ee computed, 3 the reverse.
+    # A norm that is not given is allocated here and written by the search's first pass; a given one is an input and
+    # is never overwritten.
+    compute = (1 if ee is None else 3) if xx is None else (2 if ee is None else 0)
+    if xx is None:
+        xx = torch.empty(n, dtype=torch.float32, device=x.device)
+    if ee is None:
         ee = torch.empty(padded_codes(k), dtype=torch.float32, device=x.device)
     _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
     if xx.shape[0] != n or ee.shape[0] != padded_codes(k):
@@ -125,10 +141,13 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), 1 if compute else 0, _p(ranges),
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges),
                                                      n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
                                                      _p(keys), _p(ovf), _stream(x)), "dist_argmin_filtered")
-    return (keys, ovf) if want_overflow else keys
+    out = (keys, ovf) if want_overflow else (keys,)
+    if return_norms:
+        out = out + (xx, ee)
+    return out if len(out) > 1 else keys
 
 
 def unpack_keys(keys, want_idx=True, want_dmin=False):
@@ -142,7 +161,10 @@ def unpack_keys(keys, want_idx=True, want_dmin=False):
     return idx, dmin
 
 
-def distances(x, w, xx, ee):
+def distances(x, w, xx=None, ee=None):
+    """Full [N, K] distance matrix (get_latent).  With norms given: the C ABI call; without: one op that computes them."""
+    if xx is None or ee is None:
+        return _lib.load_torch_ops().distances(x, w)
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
@@ -230,22 +252,24 @@ def forward_workspace_bytes(n: int, k: int) -> int:
     return int(_lib.load().t5vq_forward_workspace_bytes(n, k))
 
 
-def vq_forward(x, w, ranges, loss: str, *, xx=None, ste=None, q=None, diff=None, idx=None, counts=None,
-               embed_sum=None, loss_sum=None):
-    """The whole forward behind one host call (t5vq_vq_forward_f32): row norms, distance + argmin, gather /
-    straight-through / loss terms / EMA statistics, loss_sum.  Outputs are optional and caller-allocated."""
-    lib = _lib.load()
+def forward_loss_terms(n: int, with_embed_sum: bool) -> int:
+    return int(_lib.load().t5vq_forward_loss_terms(n, 1 if with_embed_sum else 0))
+
+
+def _check_forward_args(what, x, w, ranges, xx, ee, ste, q, diff, idx, counts, embed_sum, loss_terms, loss_sum):
     _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
     k = w.shape[0]
     if w.shape[1] != d:
-        raise RuntimeError("vq_forward: x and w disagree on D")
+        raise RuntimeError(f"{what}: x and w disagree on D")
     if ranges is not None:
         _need(ranges, "ranges", torch.int64, 2)
         if tuple(ranges.shape) != (n, 2):
             raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
-    for name, t, numel in (("xx", xx, n), ("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
-                           ("embed_sum", embed_sum, k * d), ("loss_sum", loss_sum, 1)):
+    for name, t, numel in (("xx", xx, n), ("ee", ee, padded_codes(k)), ("ste", ste, n * d), ("q", q, n * d),
+                           ("diff", diff, n * d), ("counts", counts, k), ("embed_sum", embed_sum, k * d),
+                           ("loss_terms", loss_terms, forward_loss_terms(n, embed_sum is not None)),
+                           ("loss_sum", loss_sum, 1)):
         if t is not None:
             _need(t, name)
             if t.numel() != numel:
@@ -254,56 +278,51 @@ def vq_forward(x, w, ranges, loss: str, *, xx=None, ste=None, q=None, diff=None,
         _need(idx, "idx", torch.int64)
         if idx.numel() != n:
             raise RuntimeError(f"idx: expected {n} elements")
+    return n, k, d
+
+
+def vq_forward(x, w, ranges, loss: str, *, xx=None, ee=None, ste=None, q=None, diff=None, idx=None, counts=None,
+               embed_sum=None, loss_terms=None, loss_sum=None):
+    """The whole forward behind one host call (t5vq_vq_forward_f32, ctypes route): row norms, distance + argmin,
+    gather / straight-through / loss terms / EMA statistics (, loss_sum).  Outputs are optional and caller-allocated."""
+    lib = _lib.load()
+    n, k, d = _check_forward_args("vq_forward", x, w, ranges, xx, ee, ste, q, diff, idx, counts, embed_sum, loss_terms,
+                                  loss_sum)
     nbytes = forward_workspace_bytes(n, k)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), _p(xx), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
-                                           _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
-                                           _p(loss_sum), _stream(x)), "vq_forward")
+        _lib.check(lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), _p(xx), _p(ee), n, k, d, LOSS_KINDS[loss], _p(ws),
+                                           nbytes, _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
+                                           _p(loss_terms), _p(loss_sum), _stream(x)), "vq_forward")
 
 
-def vq_forward_filtered(x, w, ranges, loss: str, *, ste=None, q=None, diff=None, idx=None, counts=None,
-                        embed_sum=None, loss_sum=None):
+def vq_forward_filtered(x, w, ranges, loss: str, *, xx=None, ee=None, ste=None, q=None, diff=None, idx=None,
+                        counts=None, embed_sum=None, loss_terms=None, loss_sum=None):
     """vq_forward with the filtered search (t5vq_vq_forward_filtered_f32): same outputs, one host call.  Returns the
     device int32[1] count of tokens the filter left to the scan kernel."""
     lib = _lib.load()
-    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
-    n, d = x.shape
-    k = w.shape[0]
-    if w.shape[1] != d:
-        raise RuntimeError("vq_forward_filtered: x and w disagree on D")
+    n, k, d = _check_forward_args("vq_forward_filtered", x, w, ranges, xx, ee, ste, q, diff, idx, counts, embed_sum,
+                                  loss_terms, loss_sum)
     if d % 64 or d > 4096:
         raise RuntimeError("the filtered search needs D % 64 == 0, D <= 4096")
-    if ranges is not None:
-        _need(ranges, "ranges", torch.int64, 2)
-        if tuple(ranges.shape) != (n, 2):
-            raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
-    for name, t, numel in (("ste", ste, n * d), ("q", q, n * d), ("diff", diff, n * d), ("counts", counts, k),
-                           ("embed_sum", embed_sum, k * d), ("loss_sum", loss_sum, 1)):
-        if t is not None:
-            _need(t, name)
-            if t.numel() != numel:
-                raise RuntimeError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
-    if idx is not None:
-        _need(idx, "idx", torch.int64)
-        if idx.numel() != n:
-            raise RuntimeError(f"idx: expected {n} elements")
     nbytes = int(lib.t5vq_forward_filtered_workspace_bytes(n, k, d))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_vq_forward_filtered_f32(_p(x), _p(w), _p(ranges), n, k, d, LOSS_KINDS[loss], _p(ws), nbytes,
-                                                    _p(ste), _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum),
-                                                    _p(loss_sum), _p(ovf), _stream(x)), "vq_forward_filtered")
+        _lib.check(lib.t5vq_vq_forward_filtered_f32(_p(x), _p(w), _p(ranges), _p(xx), _p(ee), n, k, d, LOSS_KINDS[loss],
+                                                    _p(ws), nbytes, _p(ste), _p(q), _p(diff), _p(idx), _p(counts),
+                                                    _p(embed_sum), _p(loss_terms), _p(loss_sum), _p(ovf), _stream(x)),
+                   "vq_forward_filtered")
     return ovf
 
 
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: int, loss_denom: float, decay: float,
                  one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float,
-                 plain_variant: bool, update: bool, scalars):
-    """EMA update (if ``update``) + loss / perplexity scalars behind one host call (t5vq_vq_ema_finalize_f32)."""
+                 plain_variant: bool, update: bool, scalars, ee_out=None):
+    """EMA update (if ``update``) + loss / perplexity scalars behind one host call (t5vq_vq_ema_finalize_f32, ctypes
+    route).  ``loss_sum``: one ready sum, or the forward's unreduced loss terms (all its elements are added up)."""
     lib = _lib.load()
-    _need(scalars, "scalars"), _need(counts, "counts")
+    _need(scalars, "scalars"), _need(counts, "counts"), _need(loss_sum, "loss_sum")
     k = counts.numel()
     d = 0
     if update:
@@ -312,13 +331,59 @@ def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: 
         if tuple(ema_w.shape) != (k, d) or tuple(w.shape) != (k, d) or embed_sum.numel() != k * d \
                 or cluster_size.numel() != k:
             raise RuntimeError("ema_finalize: inconsistent shapes")
+    if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
+        raise RuntimeError("ee_out must hold at least K norms")
     with torch.cuda.device(scalars.device):
         _lib.check(lib.t5vq_vq_ema_finalize_f32(_p(cluster_size) if update else None, _p(ema_w) if update else None,
                                                 _p(w) if update else None, _p(counts),
-                                                _p(embed_sum) if update else None, _p(loss_sum), k, d, n_tokens,
-                                                loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                                                _p(embed_sum) if update else None, _p(loss_sum), loss_sum.numel(), k, d,
+                                                n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
                                                 commitment_cost, 1 if plain_variant else 0, 1 if update else 0,
-                                                _p(scalars), _stream(scalars)), "ema_finalize")
+                                                _p(scalars), _p(ee_out) if update else None, _stream(scalars)),
+                   "ema_finalize")
+
+
+# ---- the module's route: torch.ops.t5vq (csrc/t5vq_torch.cpp) ---------------------------------------------------
+def stats_layout(n: int, k: int, d: int, with_embed_sum: bool):
+    """(embed_sum elements, counts offset, loss_sum offset, loss-terms offset, number of loss terms) of the statistics
+    buffer the fused ops return: [embed_sum K*D | counts K | loss_sum 1 | pad | loss terms].  Mirrors StatsLayout in
+    csrc/t5vq_torch.cpp; the head [0, K*D + K + 1) is what a token-sharded run all-reduces."""
+    kd = k * d if with_embed_sum else 0
+    loss_off = kd + k
+    terms_off = (loss_off + 1 + 3) // 4 * 4
+    return kd, kd, loss_off, terms_off, forward_loss_terms(n, with_embed_sum)
+
+
+def code_sqnorms(w):
+    """|e_k|^2 in the padded layout the searches take (+inf beyond K)."""
+    return _lib.load_torch_ops().code_sqnorms(w)
+
+
+def fused_forward(x, w, ranges, loss: str, *, xx=None, ee=None, filtered=False, want_diff=False, want_q=False,
+                  want_embed_sum=False, reduce_loss=False):
+    """(ste, idx, diff | None, q | None, stats, unsettled | None): t5vq::vq_forward."""
+    return _lib.load_torch_ops().vq_forward(x, w, ranges, xx, ee, LOSS_KINDS[loss], filtered, want_diff, want_q,
+                                            want_embed_sum, reduce_loss)
+
+
+def fused_finalize(cluster_size, ema_w, w, stats, n_local: int, k: int, d: int, with_embed_sum: bool,
+                   reduced_loss: bool, n_tokens: int, loss_denom: float, decay: float, one_minus_decay: float,
+                   epsilon: float, k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool,
+                   ee_out=None):
+    """scalars [loss, perplexity, n, raw latent loss]: t5vq::vq_finalize."""
+    return _lib.load_torch_ops().vq_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum, reduced_loss,
+                                             n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                                             commitment_cost, plain_variant, update, ee_out)
+
+
+def fused_step(x, w, ranges, loss: str, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False,
+               want_diff=False, want_q=False, loss_denom: float, decay: float, one_minus_decay: float, epsilon: float,
+               k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool, ee_out=None):
+    """(ste, idx, diff | None, q | None, scalars, unsettled | None, loss, perplexity): the whole module call on one GPU
+    behind one op (t5vq::vq_step = vq_forward + vq_finalize); loss / perplexity are 0-dim tensors over scalars[0..1]."""
+    return _lib.load_torch_ops().vq_step(x, w, ranges, xx, ee, cluster_size, ema_w, LOSS_KINDS[loss], filtered,
+                                         want_diff, want_q, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                                         commitment_cost, plain_variant, update, ee_out)
 
 
 def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: bool = True):
@@ -369,22 +434,26 @@ def reduce_partials(partials, out):
 def ema_cluster(cluster_size, counts, loss_sum, k: int, n_tokens: int, loss_denom: float, decay: float,
                 one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float, plain_variant: bool,
                 mode: int, scalars):
+    """``loss_sum``: one ready sum or unreduced loss terms (every element is added up, fixed order)."""
     lib = _lib.load()
     _need(scalars, "scalars")
     with torch.cuda.device(scalars.device):
-        _lib.check(lib.t5vq_ema_cluster_f32(_p(cluster_size), _p(counts), _p(loss_sum), k, n_tokens, loss_denom,
+        _lib.check(lib.t5vq_ema_cluster_f32(_p(cluster_size), _p(counts), _p(loss_sum),
+                                            loss_sum.numel() if loss_sum is not None else 0, k, n_tokens, loss_denom,
                                             decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
                                             1 if plain_variant else 0, mode, _p(scalars), _stream(scalars)),
                    "ema_cluster")
 
 
-def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: float):
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: float, ee_out=None):
     lib = _lib.load()
     _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum, "embed_sum"), _need(cluster_size, "cs")
     k, d = ema_w.shape
+    if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
+        raise RuntimeError("ee_out must hold at least K norms")
     with torch.cuda.device(w.device):
         _lib.check(lib.t5vq_ema_embed_f32(_p(ema_w), _p(w), _p(embed_sum), _p(cluster_size), k, d, decay,
-                                          one_minus_decay, _stream(w)), "ema_embed")
+                                          one_minus_decay, _p(ee_out), _stream(w)), "ema_embed")
 
 
 def max_norm(xx):
@@ -411,66 +480,32 @@ def embed_sum_fixed(x, keys, max_bits, k: int, stats_begin: int = 0, stats_count
     return out
 
 
-def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay: float, one_minus_decay: float):
+def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay: float, one_minus_decay: float,
+                    ee_out=None):
     lib = _lib.load()
     _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum_i64, "embed_sum", torch.int64)
     _need(max_bits, "max_bits", torch.int32), _need(cluster_size, "cs")
     k, d = ema_w.shape
     if embed_sum_i64.numel() != k * d:
         raise RuntimeError("ema_embed_fixed: embed_sum must be [K, D]")
+    if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
+        raise RuntimeError("ee_out must hold at least K norms")
     with torch.cuda.device(w.device):
         _lib.check(lib.t5vq_ema_embed_fixed_f32(_p(ema_w), _p(w), _p(embed_sum_i64), _p(max_bits), _p(cluster_size), k,
-                                                d, decay, one_minus_decay, _stream(w)), "ema_embed_fixed")
+                                                d, decay, one_minus_decay, _p(ee_out), _stream(w)), "ema_embed_fixed")
 
 
 def ste_backward(g_out, diff, g_loss, coef: float):
-    lib = _lib.load()
-    _need(diff, "diff")
-    if g_out is not None:
-        g_out = _need(g_out.contiguous(), "g_out")
-    if g_loss is not None:
-        g_loss = _need(g_loss.contiguous(), "g_loss")
-    out = torch.empty_like(diff)
-    with torch.cuda.device(diff.device):
-        _lib.check(lib.t5vq_ste_backward_f32(_p(g_out), _p(diff), _p(g_loss), coef, diff.numel(), _p(out),
-                                             _stream(diff)), "ste_backward")
-    return out
+    return _lib.load_torch_ops().ste_backward(g_out, diff, g_loss, coef)
 
 
 def scatter_rows(rows, idx, k: int, scale_dev=None, scale_host: float = 1.0):
-    lib = _lib.load()
-    _need(rows, "rows", ndim=2), _need(idx, "idx", torch.int64)
-    n, d = rows.shape
-    out = torch.empty(k, d, dtype=torch.float32, device=rows.device)
-    if scale_dev is not None:
-        scale_dev = _need(scale_dev.contiguous(), "scale_dev")
-    with torch.cuda.device(rows.device):
-        _lib.check(lib.t5vq_scatter_rows_f32(_p(rows), _p(idx), _p(scale_dev), scale_host, n, k, d, _p(out),
-                                             _stream(rows)), "scatter_rows")
-    return out
+    return _lib.load_torch_ops().scatter_rows(rows, idx, scale_dev, scale_host, k)
 
 
 def cosine_backward(x, q, g_out, g_loss, coef_x: float, coef_q: float, want_grad_q: bool):
-    lib = _lib.load()
-    _need(x, "x", ndim=2), _need(q, "q", ndim=2)
-    n, d = x.shape
-    if g_out is not None:
-        g_out = _need(g_out.contiguous(), "g_out")
-    if g_loss is not None:
-        g_loss = _need(g_loss.contiguous(), "g_loss")
-    gx = torch.empty_like(x)
-    gq = torch.empty_like(x) if want_grad_q else None
-    with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_cosine_backward_f32(_p(x), _p(q), _p(g_out), _p(g_loss), coef_x, coef_q, n, d, _p(gx),
-                                                _p(gq), _stream(x)), "cosine_backward")
-    return gx, gq
+    return _lib.load_torch_ops().cosine_backward(x, q, g_out, g_loss, coef_x, coef_q, want_grad_q)
 
 
 def one_hot(idx, k: int):
-    lib = _lib.load()
-    _need(idx, "idx", torch.int64)
-    n = idx.numel()
-    enc = torch.empty(n, k, dtype=torch.float32, device=idx.device)
-    with torch.cuda.device(idx.device):
-        _lib.check(lib.t5vq_one_hot_f32(_p(idx), n, k, _p(enc), _stream(idx)), "one_hot")
-    return enc
+    return _lib.load_torch_ops().one_hot(idx.reshape(-1), k)

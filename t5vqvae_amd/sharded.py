@@ -154,7 +154,9 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         elif update:
             ops.ema_embed(self._ema_w.data, self._embedding.weight.data, embed_sum, self._ema_cluster_size,
                           plan.decay, 1 - plan.decay)
-        return {"scalars": scalars, "ste": ste, "idx": idx, "diff": diff, "q": q, "dims": (n, d, k, plan.batch)}
+        self._last_scalars = scalars
+        return {"loss": vqvae._scalar_of(scalars, 0), "ppl": vqvae._scalar_of(scalars, 1), "ste": ste, "idx": idx,
+                "diff": diff, "q": q, "dims": (n, d, k, plan.batch)}
 
     # --- evaluation helpers over the sharded codebook ------------------------------------------------
     @torch.no_grad()

@@ -11,6 +11,10 @@ LOSS_KINDS = {"mse": 0, "cosine": 1}
 KEY_NONE = 0x7FFFFFFFFFFFFFFF
 
 
+def require_device(t, name):
+    pass
+
+
 def padded_codes(k):
     return (k + 127) // 128 * 128
 
@@ -63,8 +67,8 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True, ranges=None,
                          code_offset=0):
-    if xx is None or ee is None:
-        xx, ee = row_sqnorms(x, w)
+    xx_, ee_ = row_sqnorms(x, w)
+    xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
     out = dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, keys=keys)
     return (out, torch.zeros(1, dtype=torch.int32)) if want_overflow else out
 
@@ -78,7 +82,9 @@ def unpack_keys(keys, want_idx=True, want_dmin=False):
     return idx, dmin
 
 
-def distances(x, w, xx, ee):
+def distances(x, w, xx=None, ee=None):
+    if xx is None or ee is None:
+        xx, ee = row_sqnorms(x, w)
     return (xx.unsqueeze(1) + ee[:w.shape[0]]) - 2 * (x @ w.t())
 
 
@@ -125,31 +131,88 @@ def order_by_code(keys, k):
     return torch.argsort((keys & 0xFFFFFFFF).clamp(0, k - 1), stable=True).to(torch.int32)
 
 
-def vq_forward(x, w, ranges, loss, *, xx=None, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
-               loss_sum=None):
-    xx_, ee = row_sqnorms(x, w)
-    xx = xx_ if xx is None else xx
+def forward_loss_terms(n, with_embed_sum):
+    return n if (with_embed_sum and n >= ORDER_MIN_TOKENS) else gather_blocks(n)
+
+
+def vq_forward(x, w, ranges, loss, *, xx=None, ee=None, ste=None, q=None, diff=None, idx=None, counts=None,
+               embed_sum=None, loss_terms=None, loss_sum=None):
+    xx_, ee_ = row_sqnorms(x, w)
+    xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
     keys = dist_argmin(x, w, xx, ee, ranges)
-    partial = torch.empty(gather_blocks(x.shape[0])) if loss_sum is not None else None
+    n = x.shape[0]
+    perm = order_by_code(keys, w.shape[0]) if (embed_sum is not None and n >= ORDER_MIN_TOKENS) else None
+    partial = loss_terms
+    if partial is None and loss_sum is not None:
+        partial = torch.empty(forward_loss_terms(n, embed_sum is not None))
     gather_stats(x, w, keys, loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts, embed_sum=embed_sum,
-                 loss_partial=partial)
+                 loss_partial=partial, perm=perm)
     if loss_sum is not None:
         reduce_partials(partial, loss_sum)
 
 
-def vq_forward_filtered(x, w, ranges, loss, *, ste=None, q=None, diff=None, idx=None, counts=None, embed_sum=None,
-                        loss_sum=None):
-    vq_forward(x, w, ranges, loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts, embed_sum=embed_sum,
-               loss_sum=loss_sum)
+def vq_forward_filtered(x, w, ranges, loss, **kw):
+    vq_forward(x, w, ranges, loss, **kw)
     return torch.zeros(1, dtype=torch.int32)
 
 
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens, loss_denom, decay, one_minus_decay,
-                 epsilon, k_epsilon, commitment_cost, plain_variant, update, scalars):
+                 epsilon, k_epsilon, commitment_cost, plain_variant, update, scalars, ee_out=None):
     ema_cluster(cluster_size if update else None, counts, loss_sum, counts.numel(), n_tokens, loss_denom, decay,
                 one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, 1 if update else 0, scalars)
     if update:
-        ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay)
+        ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay, ee_out)
+
+
+# ---- the module's route (t5vqvae_amd.ops.fused_*: torch.ops.t5vq in the product) ------------------------------
+def stats_layout(n, k, d, with_embed_sum):
+    kd = k * d if with_embed_sum else 0
+    loss_off = kd + k
+    terms_off = (loss_off + 1 + 3) // 4 * 4
+    return kd, kd, loss_off, terms_off, forward_loss_terms(n, with_embed_sum)
+
+
+def code_sqnorms(w):
+    return row_sqnorms(None, w)[1]
+
+
+def fused_forward(x, w, ranges, loss, *, xx=None, ee=None, filtered=False, want_diff=False, want_q=False,
+                  want_embed_sum=False, reduce_loss=False):
+    n, d = x.shape
+    k = w.shape[0]
+    kd, counts_off, loss_off, terms_off, n_terms = stats_layout(n, k, d, want_embed_sum)
+    stats = torch.full((terms_off + n_terms,), float("nan"))
+    ste, idx = torch.empty_like(x), torch.empty(n, dtype=torch.int64)
+    diff = torch.empty_like(x) if want_diff else None
+    q = torch.empty_like(x) if want_q else None
+    vq_forward(x, w, ranges, loss, xx=xx, ee=ee, ste=ste, q=q, diff=diff, idx=idx,
+               counts=stats[counts_off:counts_off + k], embed_sum=stats[:kd].view(k, d) if kd else None,
+               loss_terms=stats[terms_off:terms_off + n_terms],
+               loss_sum=stats[loss_off:loss_off + 1] if reduce_loss else None)
+    return ste, idx, diff, q, stats, (torch.zeros(1, dtype=torch.int32) if filtered else None)
+
+
+def fused_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum, reduced_loss, n_tokens, loss_denom,
+                   decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, update, ee_out=None):
+    kd, counts_off, loss_off, terms_off, n_terms = stats_layout(n_local, k, d, with_embed_sum)
+    assert stats.numel() == terms_off + n_terms
+    scalars = torch.empty(4)
+    loss_in = stats[loss_off:loss_off + 1] if reduced_loss else stats[terms_off:terms_off + n_terms]
+    ema_finalize(cluster_size, ema_w, w, stats[counts_off:counts_off + k], stats[:kd].view(k, d) if kd else None,
+                 loss_in, n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
+                 plain_variant, update, scalars, ee_out)
+    return scalars
+
+
+def fused_step(x, w, ranges, loss, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False, want_diff=False,
+               want_q=False, loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
+               update, ee_out=None):
+    ste, idx, diff, q, stats, ovf = fused_forward(x, w, ranges, loss, xx=xx, ee=ee, filtered=filtered,
+                                                  want_diff=want_diff, want_q=want_q, want_embed_sum=update)
+    scalars = fused_finalize(cluster_size, ema_w, w if update else None, stats, x.shape[0], w.shape[0], x.shape[1],
+                             update, False, x.shape[0], loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
+                             commitment_cost, plain_variant, update, ee_out)
+    return ste, idx, diff, q, scalars, ovf, scalars[0].clone(), scalars[1].clone()
 
 
 def rmsnorm_sqnorms(hidden, gamma, keep, scale, eps, want_rms=True):
@@ -188,7 +251,7 @@ def ema_cluster(cluster_size, counts, loss_sum, k, n_tokens, loss_denom, decay, 
         n = scalars[2].clone()
     if mode in (1, 3) and cluster_size is not None:
         cluster_size.copy_((cluster_size + f(epsilon)) / (n + f(k_epsilon)) * n)
-    m = loss_sum[0] / f(loss_denom) if loss_sum is not None else f(0.0)
+    m = loss_sum.double().sum().float() / f(loss_denom) if loss_sum is not None else f(0.0)
     cm = f(commitment_cost) * m
     scalars[0] = m + cm if plain_variant else cm
     scalars[1] = ent.float() if mode == 2 else torch.exp(-ent.float())
@@ -196,10 +259,12 @@ def ema_cluster(cluster_size, counts, loss_sum, k, n_tokens, loss_denom, decay, 
     scalars[3] = m
 
 
-def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay):
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay, ee_out=None):
     f = lambda v: torch.tensor(v, dtype=torch.float32)
     ema_w.copy_(ema_w * f(decay) + f(one_minus_decay) * embed_sum)
     w.copy_(ema_w / cluster_size.unsqueeze(1))
+    if ee_out is not None:
+        ee_out[:w.shape[0]] = (w * w).sum(1)
 
 
 def _fixed_shift(max_bits):
@@ -220,9 +285,9 @@ def embed_sum_fixed(x, keys, max_bits, k, stats_begin=0, stats_count=None):
     return torch.zeros(stats_count, x.shape[1], dtype=torch.int64).index_add_(0, i[inside], q[inside])
 
 
-def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay, one_minus_decay):
+def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay, one_minus_decay, ee_out=None):
     dw = (embed_sum_i64.double() * 2.0 ** -_fixed_shift(max_bits)).float()
-    ema_embed(ema_w, w, dw, cluster_size, decay, one_minus_decay)
+    ema_embed(ema_w, w, dw, cluster_size, decay, one_minus_decay, ee_out)
 
 
 def ste_backward(g_out, diff, g_loss, coef):

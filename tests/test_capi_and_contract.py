@@ -43,14 +43,29 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 4096, 0, None, None, None, None, 0, 4, None, None, None,
                                      None, None) == 1                               # D > 2048
     assert lib.t5vq_order_by_code(p, 4, 4, None, p, None) == 1
-    assert lib.t5vq_ema_cluster_f32(None, p, None, 4, 4, 1.0, .99, .01, 1e-5, 4e-5, .25, 0, 9, p, None) == 1
+    assert lib.t5vq_ema_cluster_f32(None, p, None, 0, 4, 4, 1.0, .99, .01, 1e-5, 4e-5, .25, 0, 9, p, None) == 1
     # composite forwards: workspace checks come before any launch
-    assert lib.t5vq_vq_forward_f32(p, p, None, None, 4, 4, 8, 0, None, 0, None, None, None, None, None, None, None,
-                                   None) == 1
+    assert lib.t5vq_vq_forward_f32(p, p, None, None, None, 4, 4, 8, 0, None, 0, None, None, None, None, None, None, None,
+                                   None, None) == 1
     assert lib.t5vq_forward_filtered_workspace_bytes(4096, 512, 768) > lib.t5vq_forward_workspace_bytes(4096, 512)
-    assert lib.t5vq_vq_forward_filtered_f32(p, p, None, 4, 4, 64, 0, None, 0, None, None, None, None, None, None, None,
-                                            None, None) == 1
+    assert lib.t5vq_vq_forward_filtered_f32(p, p, None, None, None, 4, 4, 64, 0, None, 0, None, None, None, None, None,
+                                            None, None, None, None, None) == 1
     assert b"workspace" in lib.t5vq_last_error()
+
+
+def test_torch_extension_loads_and_registers_every_op():
+    """The PyTorch-ROCm extension (csrc/t5vq_torch.cpp) loads without a GPU, registers the ops the modules call, and
+    refuses CPU tensors with a clear message (no compute here)."""
+    import torch
+    from t5vqvae_amd import _lib
+    ops = _lib.load_torch_ops()
+    for name in ("vq_forward", "vq_finalize", "vq_step", "ste_backward", "scatter_rows", "cosine_backward",
+                 "distances", "one_hot", "code_sqnorms"):
+        assert hasattr(ops, name), name
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.code_sqnorms(torch.zeros(4, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.distances(torch.zeros(4, 8), torch.zeros(3, 8))
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -59,6 +74,11 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libt5vq.so")
     with pytest.raises(_lib.T5VQError, match="no CPU fallback"):
         _lib.load()
+    monkeypatch.undo()
+    monkeypatch.setattr(_lib, "_torch_ops", None)
+    monkeypatch.setattr(_lib, "TORCH_LIB_PATH", "/nonexistent/libt5vq_torch.so")
+    with pytest.raises(_lib.T5VQError, match="no CPU fallback"):
+        _lib.load_torch_ops()
 
 
 def test_module_contract_matches_reference_signatures():

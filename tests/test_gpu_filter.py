@@ -150,10 +150,14 @@ def test_filter_computes_the_same_row_norms_itself():
     x = synth.normal((n, d), 91, 0, device="cuda")
     w = synth.normal((k, d), 92, 0, device="cuda")
     xx, ee = ops.row_sqnorms(x, w)
-    xx2 = torch.empty_like(xx)
     k1 = ops.dist_argmin_filtered(x, w, xx, ee)
-    k2 = ops.dist_argmin_filtered(x, w, xx2, None)        # norms written by the call's own first pass
-    assert torch.equal(k1, k2) and torch.equal(xx, xx2)
+    # norms that are not given are written by the call's own first pass, bit-identical to row_sqnorms; given ones
+    # are inputs and stay untouched (all four combinations of the C ABI's compute_norms)
+    for gx, ge in ((None, None), (xx, None), (None, ee)):
+        keep_x, keep_e = xx.clone(), ee.clone()
+        k2, xx2, ee2 = ops.dist_argmin_filtered(x, w, gx, ge, return_norms=True)
+        assert torch.equal(k1, k2) and torch.equal(xx, xx2) and torch.equal(ee, ee2)
+        assert torch.equal(xx, keep_x) and torch.equal(ee, keep_e)
 
 
 @pytest.mark.parametrize("n,k,d,offset", [(4096, 2048, 768, 0), (1000, 700, 128, 0), (3000, 1024, 768, 1024),

@@ -103,9 +103,11 @@ def _token_sharded_worker(rank, world, port, q, deterministic=False):
         errs += [rel(loss, o.loss), rel(ppl, o.perplexity),
                  rel(qz, o.quantized[rank * 2:(rank + 1) * 2])]
         assert torch.equal(enc.argmax(1), o.indices.view(4, -1)[rank * 2:(rank + 1) * 2].reshape(-1))
-        # gradient of the GLOBAL-mean commitment loss w.r.t. the local tokens (q_raw = the step's quantized)
+        # gradient of the GLOBAL-mean commitment loss w.r.t. the local tokens (q_raw = the step's quantized), times
+        # the group size: the default convention ("mean") expects the caller to average parameter gradients over the
+        # group, as DistributedDataParallel does
         xl = x[rank * 2:(rank + 1) * 2]
-        g_ref = 1.0 + 1.5 * 0.25 * 2.0 * (xl - o.extra["q_raw"][rank * 2:(rank + 1) * 2]) / (N * D)
+        g_ref = 1.0 + world * 1.5 * 0.25 * 2.0 * (xl - o.extra["q_raw"][rank * 2:(rank + 1) * 2]) / (N * D)
         errs.append(rel(xs.grad, g_ref))
     errs += [rel(m._ema_cluster_size, st.cluster_size), rel(m._ema_w.data, st.ema_w),
              rel(m._embedding.weight.data, st.weight)]
@@ -127,6 +129,48 @@ def _token_sharded_worker(rank, world, port, q, deterministic=False):
             single(synth.normal((4, N // 4, D), 2, t))
         for name, tns in m.state_dict().items():
             assert torch.equal(tns, single.state_dict()[name]), name
+    q.put((rank, max(errs)))
+    dist.destroy_process_group()
+
+
+def _plain_token_sharded_worker(rank, world, port, q, reduction):
+    """Plain VectorQuantizer (codebook learned by gradient), token-sharded over 2 ranks: the gradients to the local
+    inputs and to the (replicated) codebook, reduced over the group the way ``gradient_reduction`` announces, must
+    equal the oracle's gradients on the concatenated batch (vqvae/vqvae.py:55-56,69,71 under autograd)."""
+    _init(rank, world, port)
+    from t5vqvae_amd import VectorQuantizer
+    from t5vqvae_amd.sharded import shard_tokens
+    m = VectorQuantizer(K, D, 0.25)
+    w0 = synth.normal((K, D), 1, 0)
+    with torch.no_grad():
+        m._embedding.weight.copy_(w0)
+    shard_tokens(m)
+    m.gradient_reduction = reduction
+    m.train()
+    x = synth.normal((4, N // 4, D), 2, 0)
+    # oracle: one process, whole batch.  The straight-through output passes its gradient to the inputs unchanged
+    # (vqvae/vqvae.py:71), so the oracle only has to provide the gradient of the loss term; gq (a weight on every
+    # output element, scaled to the loss gradient's magnitude so neither part drowns the other) is added by hand.
+    gq = synth.normal((4, N // 4, D), 2, 5) * 1e-5
+    st = vo.VQState(w0.clone().requires_grad_(True))
+    xr = x.clone().requires_grad_(True)
+    o = vo.faithful_forward(st, xr, ema=False, training=True, commitment_cost=0.25)
+    (o.loss * 1.5).backward()
+    # sharded: each rank back-propagates through its own tokens only
+    xs = x[rank * 2:(rank + 1) * 2].clone().requires_grad_(True)
+    loss, qz, ppl, enc = m(xs)
+    (loss * 1.5 + (qz * gq[rank * 2:(rank + 1) * 2]).sum()).backward()
+    errs = [rel(loss, o.loss)]
+    gw = m._embedding.weight.grad.clone()
+    dist.all_reduce(gw, op=dist.ReduceOp.SUM)
+    if reduction == "mean":
+        gw /= world                       # what DistributedDataParallel does with the codebook gradient
+    errs.append(rel(gw, st.weight.grad))
+    # inputs: a parameter upstream sees sum_r J_r^T gx_r and, under "mean", divides by the group size -- so the loss
+    # part of gx_r carries the factor `world` against the single-process rows; the part that came in through the
+    # straight-through output is this rank's own downstream gradient and passes unchanged
+    scale = world if reduction == "mean" else 1
+    errs.append(rel(xs.grad, gq[rank * 2:(rank + 1) * 2] + scale * xr.grad[rank * 2:(rank + 1) * 2]))
     q.put((rank, max(errs)))
     dist.destroy_process_group()
 
@@ -182,9 +226,15 @@ def _run(worker, *args):
     procs = [ctx.Process(target=worker, args=(r, 2, port, q) + args) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(180)
-        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    try:
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    finally:
+        for p in procs:               # a hung worker must not outlive the test
+            if p.is_alive():
+                p.kill()
+                p.join()
     res = dict(q.get(timeout=5) for _ in range(2))
     assert set(res) == {0, 1}
     assert max(res.values()) <= TOL, res
@@ -193,6 +243,11 @@ def _run(worker, *args):
 @pytest.mark.parametrize("deterministic", [False, True])
 def test_token_sharded_equals_single_process_gloo(deterministic):
     _run(_token_sharded_worker, deterministic)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_token_sharded_plain_variant_gradients_gloo(reduction):
+    _run(_plain_token_sharded_worker, reduction)
 
 
 @pytest.mark.parametrize("roles,training", [(None, True), (None, False),

@@ -32,14 +32,14 @@ def _run(lib, x, w, ranges, noalloc):
     k = w.shape[0]
     o = _outputs(n, k, d, x.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    tail = (_p(o["ste"]), None, _p(o["diff"]), _p(o["idx"]), _p(o["counts"]), _p(o["embed_sum"]), _p(o["loss_sum"]),
-            stream)
+    tail = (_p(o["ste"]), None, _p(o["diff"]), _p(o["idx"]), _p(o["counts"]), _p(o["embed_sum"]), None,
+            _p(o["loss_sum"]), stream)
     if noalloc:
-        rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(w), _p(ranges), None, n, k, d, 0, *tail)
+        rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(w), _p(ranges), None, None, n, k, d, 0, *tail)
     else:
         nbytes = int(lib.t5vq_forward_workspace_bytes(n, k))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        rc = lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), None, n, k, d, 0, _p(ws), nbytes, *tail)
+        rc = lib.t5vq_vq_forward_f32(_p(x), _p(w), _p(ranges), None, None, n, k, d, 0, _p(ws), nbytes, *tail)
     _lib.check(rc, "noalloc" if noalloc else "workspace")
     torch.cuda.synchronize()
     return o
@@ -80,8 +80,8 @@ def test_noalloc_forward_refuses_shapes_beyond_the_scratch():
     n, k, d = 1 << 20, 16384, 768          # 20 N + 8 K = 21 MB of temporaries > 4 MiB; refused before any launch
     assert int(lib.t5vq_forward_workspace_bytes(n, k)) > (4 << 20)
     x = torch.empty(16, d, device=dev)     # never dereferenced: the size check comes first
-    rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(x), None, None, n, k, d, 0, None, None, None, None, None, None, None,
-                                         None)
+    rc = lib.t5vq_vq_forward_noalloc_f32(_p(x), _p(x), None, None, None, n, k, d, 0, None, None, None, None, None, None,
+                                         None, None, None)
     assert rc == 1
     msg = lib.t5vq_last_error().decode()
     assert "T5VQ_NOALLOC_SCRATCH_BYTES" in msg and "t5vq_vq_forward_f32" in msg
