@@ -1,20 +1,35 @@
 """Benchmark of the VQ bottleneck hot path (fused forward + EMA codebook update) on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W --workload c3|c4|c1|c2 --regime uniform|cold]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W --workload auto|c1|c2|c3|c4|c5 --regime uniform|cold|collapsed]
 
-A step = one ``VectorQuantizerEMA.forward`` in training mode (distance + argmin + gather + loss + perplexity
-+ EMA update) over one resident batch of synthetic tokens.  Default workload: BASELINE config 3 per GPU
-(N=65536 tokens/GPU, K=8192, D=768); with N GPUs the tokens are sharded (weak scaling: 65536 tokens per
-rank) and the EMA statistics are all-reduced over RCCL each step.  Prints ONE JSON line on rank 0.
+A step = one ``VectorQuantizerEMA.forward`` in training mode (distance + argmin + gather + loss + perplexity + EMA
+update) over one resident batch of synthetic tokens.  Prints ONE JSON line (rank 0).
+
+Launching.  ``--gpus 1`` runs in this process.  ``--gpus N`` (N > 1) without a launcher: this process starts N fresh
+child processes BEFORE it touches the GPU (it never re-executes itself), one rank per GPU, rendezvous on 127.0.0.1 over
+RCCL, and relays rank 0's line.  Under ``python -m torch.distributed.run`` (RANK / WORLD_SIZE in the environment) the
+process is a rank and does not spawn.  ``T5VQ_BENCH_FORCE_DIST=1`` takes the RCCL path at world size 1 (rehearsal on a
+one-GPU box); ``--dry-run`` drives spawn + rendezvous + the statistics all-reduce on CPU over gloo with a test stand-in
+for the kernels (no number it prints is a measurement).
+
+Workloads (BASELINE.json configs; D = 768, fp32):
+  c3  N = 65536 tokens per GPU, K = 8192 (config 3): the headline at --gpus 1; with N GPUs token-sharded, WEAK scaling
+  c4  N = 2^20 tokens in total, N/G per GPU, K = 16384 (config 4): token-sharded, STRONG scaling -- the default for N > 1
+  c5  K = 65536 codes sharded K/G per GPU, N = 65536 tokens replicated (config 5): global argmin across shards, and the
+      disentangled grouped forms (8 role ranges aligned to the shards, 5 unequal ranges that straddle them)
+  c1  N = 2880, K = 10000 (published training shape, config 1);  c2  N = 4096, K = 512 forward only (config 2)
+At --gpus 1 the line also carries `configs`: every other single-GPU configuration (and the assignment regimes of c3)
+measured one call at a time -- HIP events around the call, state reset outside the timed region, median / min -- with
+its roofline fractions and a parity check against the CPU oracle on a token slice.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -24,71 +39,170 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA, same guide
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (tokens per GPU, K, D, update, description)
+    # name: (tokens per GPU, K, D, update, description)  -- single-GPU shapes; c4 here is ONE GPU's share at 8 GPUs
     "c1": (2880, 10000, 768, True, "C1 published training shape N=2880 K=10000 fwd+EMA"),
     "c2": (4096, 512, 768, False, "C2 N=4096 K=512 fwd only"),
     "c3": (65536, 8192, 768, True, "C3 N=65536/GPU K=8192 D=768 fused fwd+EMA"),
     "c4": (131072, 16384, 768, True, "C4 share N=2^20/8 per GPU K=16384 D=768 fused fwd+EMA"),
 }
+C4_TOTAL_TOKENS = 1 << 20
+C5_TOKENS, C5_CODES = 65536, 65536
 
 
-def build_state(workload, regime, rank, world, dev):
-    from t5vqvae_amd import synth
-    n, k, d, update, _ = WORKLOADS[workload]
+# =====================================================================================================
+# launcher (parent process: no GPU call, no torch import)
+# =====================================================================================================
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, argv):
+    """Start one child per rank (fresh interpreters, this script, same arguments) and relay their output; rank 0 prints
+    the JSON line.  The parent has not initialised the GPU and never replaces itself with another program."""
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), T5VQ_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    deadline = time.time() + float(os.environ.get("T5VQ_BENCH_TIMEOUT", "1500"))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    if code != 0:
+                        rc = rc or code
+            if rc or time.time() > deadline:
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                      # exactly the children started above
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
+
+
+# =====================================================================================================
+# state, regimes
+# =====================================================================================================
+def build_state(workload, regime, rank, world, dev, n=None, k=None):
+    """(w, ema_w, cluster_size, x) of one rank.  uniform: steady-state proxy, every code in use; cold: the
+    reference's cold start on N(0,1) inputs; collapsed: the state two reference-faithful steps after the cold start."""
+    import torch
+    from t5vqvae_amd import VectorQuantizerEMA, synth
+    wn, wk, d, update, _ = WORKLOADS[workload]
+    n, k = n or wn, k or wk
     w = synth.normal((k, d), 1000, 0, device=dev)
-    if regime == "uniform":                      # steady-state proxy: every code in use
+    if regime == "uniform":
         cs = torch.full((k,), float(n * world) / k, device=dev)
         ema_w = w * cs.unsqueeze(1)
         x, _ = synth.clustered(n, w, 0.5, 2000 + rank)
-    else:                                        # reference cold start on N(0,1) inputs
+    else:
         cs = torch.zeros(k, device=dev)
         ema_w = synth.normal((k, d), 1000, 1, device=dev)
         x = synth.normal((n, d), 2000 + rank, 0, device=dev)
+        if regime == "collapsed":
+            m = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev).train()
+            m.encodings = "indices"
+            with torch.no_grad():
+                m._embedding.weight.copy_(w), m._ema_w.copy_(ema_w), m._ema_cluster_size.copy_(cs)
+                m(x.view(1, n, d)), m(x.view(1, n, d))
+            w, ema_w, cs = m._embedding.weight.data.clone(), m._ema_w.data.clone(), m._ema_cluster_size.clone()
     x = x.view(64, n // 64, d) if n % 64 == 0 else x.view(1, n, d)
     return w, ema_w, cs, x
 
 
-def cpu_baseline(workload, dev, budget_s=20.0):
-    """CPU leg: the oracle's faithful op-for-op path (dense one-hot, three matmuls) timed on
-    the host cores on a bounded token slice of the workload -- and, on the same slice and the same initial state,
-    used as the checker of one GPU step (the parity report SURVEY.md 8d asks for beside every benchmark)."""
+def make_module(k, d, w, ema_w, cs, update, search, dev):
+    import torch
+    from t5vqvae_amd import VectorQuantizerEMA
+    mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
+    with torch.no_grad():
+        mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
+    mod.encodings = "indices"
+    mod.search = search
+    mod.train(update)
+    return mod
+
+
+def step_bytes(n, k, d, update):
+    """SURVEY 8d algorithmic bytes of the whole step (fwd: x, W, q, idx, ee; EMA: x again, ema_w r/w, W w)."""
+    b = 4.0 * (n * d + k * d + n * d) + 8.0 * n + 4.0 * k
+    if update:
+        b += 4.0 * n * d + 12.0 * k * d + 12.0 * k
+    return b
+
+
+def roofline_fracs(n, k, d, update, ms):
+    flops = 2.0 * n * k * d
+    return {"frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms * 1e-3),
+            "frac_of_hbm_roofline": step_bytes(n, k, d, update) / (PEAK_HBM_GBS * 1e9) / (ms * 1e-3),
+            "algorithmic_flops": flops, "algorithmic_bytes": step_bytes(n, k, d, update)}
+
+
+def per_call_ms(mod, x, w, ema_w, cs, iters):
+    """One call per measurement: state reset OUTSIDE the timed region, HIP events around the call on the stream the
+    kernels run on (torch's current stream is the one the extension launches on).  (median, min) in ms."""
+    import torch
+    ts = []
+    with torch.no_grad():
+        for i in range(iters + 3):
+            mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            out = mod(x)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1))
+    return statistics.median(ts), min(ts), out
+
+
+# =====================================================================================================
+# CPU leg: the oracle as baseline and as checker (the ONLY place that imports oracle/)
+# =====================================================================================================
+def cpu_leg(k, d, update, search, state, dev, slice_tokens, time_budget_s, desc):
+    """The oracle's faithful op-for-op path (dense one-hot, three matmuls) on the host cores on
+    a bounded token slice -- timed when time_budget_s > 0 -- and, on the same slice and the same initial state, the
+    checker of one GPU step taken with the benchmark's own search mode (the parity report of SURVEY.md 8d)."""
+    import torch
     from oracle import vq_oracle as vo
-    from t5vqvae_amd import VectorQuantizerEMA, synth
-    n, k, d, update, _ = WORKLOADS[workload]
-    ns = min(n, 8192)
-    w = synth.normal((k, d), 1000, 0)
-    cs = torch.full((k,), float(n) / k)
-    st0 = vo.VQState(w, w * cs.unsqueeze(1), cs)
-    x, _ = synth.clustered(ns, w, 0.5, 2000)
-    x = x.view(1, ns, d)
+    w, ema_w, cs, x = (t.detach().cpu() for t in state)
+    x = x.reshape(-1, d)
+    ns = min(x.shape[0], slice_tokens)
+    x = x[:ns].contiguous().view(1, ns, d)
+    st0 = vo.VQState(w, ema_w, cs)
     times = []
     t_start = time.perf_counter()
     with torch.no_grad():
-        for i in range(6):
+        for i in range(6 if time_budget_s > 0 else 1):
             st = st0.clone()
             t0 = time.perf_counter()
             ref = vo.faithful_forward(st, x, ema=True, training=update, commitment_cost=0.25)
             times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > budget_s and i >= 1:
+            if time.perf_counter() - t_start > time_budget_s and i >= 1:
                 break
-        # parity of one GPU step on the same slice / state
-        mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
-        mod._embedding.weight.copy_(st0.weight)
-        mod._ema_w.copy_(st0.ema_w)
-        mod._ema_cluster_size.copy_(st0.cluster_size)
-        mod.encodings = "indices"
-        mod.train(update)
+        mod = make_module(k, d, st0.weight, st0.ema_w, st0.cluster_size, update, search, dev)
         loss, q, ppl, idx = mod(x.to(dev))
         idx = idx.squeeze(1).cpu()
         outside, inside = vo.classify_mismatches(x.view(-1, d), st0.weight, idx, ref.indices)
-        chk = vo.algorithmic_forward(st0.clone(), x, ema=True, training=update, commitment_cost=0.25, indices=idx)
+        stc = st0.clone()
+        chk = vo.algorithmic_forward(stc, x, ema=True, training=update, commitment_cost=0.25, indices=idx)
 
     def rel(a, b):
         a, b = a.detach().double().cpu(), b.detach().double()
         return float((a - b).norm() / b.norm())
-    stc = st0.clone()
-    vo.algorithmic_forward(stc, x, ema=True, training=update, commitment_cost=0.25, indices=idx)
-    parity = {"tokens": ns, "idx_mismatch_outside_band": outside, "idx_mismatch_inside_band": inside,
+    parity = {"tokens": ns, "search": search, "idx_mismatch_outside_band": outside, "idx_mismatch_inside_band": inside,
               "band": "|d64(a)-d64(b)| <= 1e-6*(|x|^2+max|e|^2)",
               "rel_err": {"quantized": rel(q, chk.quantized), "loss": rel(loss, chk.loss),
                           "perplexity": rel(ppl, chk.perplexity)}}
@@ -99,15 +213,111 @@ def cpu_baseline(workload, dev, budget_s=20.0):
     tt = times[1:] or times
     med = sorted(tt)[len(tt) // 2]
     return {"value": ns / med, "unit": "vectors/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{ns}-token slice of the workload (K={k}, D={d}, fwd{'+EMA' if update else ''}), "
-                      f"median of {len(tt)} calls, torch CPU fp32, {os.cpu_count()} host CPUs visible",
+            "sample": f"{ns}-token slice of {desc} (K={k}, D={d}, fwd{'+EMA' if update else ''}), "
+                      f"median of {len(tt)} call(s), torch CPU fp32, {os.cpu_count()} host CPUs visible",
             "parity": parity}
 
 
+def c5_shard_config(dev, search, iters, check):
+    """ONE code shard of config 5 on one GPU: 8192 of 65536 codes (code_offset = shard 3), all 65536 tokens, statistics
+    for the local slice only, the two-phase cluster update (without its scalar all-reduce: no peer here).  Parity: the
+    shard's indices minus its offset against the oracle's argmin over the same code slice."""
+    import torch
+    from t5vqvae_amd import ops, synth
+    n, kl, d, k = C5_TOKENS, C5_CODES // 8, 768, C5_CODES
+    off = 3 * kl
+    w = synth.normal((kl, d), 1000, 3, device=dev)
+    x, _ = synth.clustered(n, w, 0.5, 2000)
+    cs0 = torch.full((kl,), float(n) / kl, device=dev)
+    ew0 = w * cs0.unsqueeze(1)
+    cs, ew, wl = cs0.clone(), ew0.clone(), w.clone()
+    use_filter = search != "scan"
+
+    def call():
+        ee = ops.code_sqnorms(wl)
+        if use_filter:
+            keys = ops.dist_argmin_filtered(x, wl, ee=ee, code_offset=off, exact_keys=True)
+        else:
+            keys = ops.dist_argmin(x, wl, ops.row_sqnorms(x, None)[0], ee, code_offset=off)
+        # (the all-reduce(MIN) of the keys over the shards sits here; every token of this synthetic batch is won locally)
+        local = keys - off
+        counts = torch.empty(kl, device=dev)
+        es = torch.empty(kl, d, device=dev)
+        perm = ops.order_by_code(local, kl)
+        part = torch.empty(n, device=dev)
+        ste = torch.empty_like(x)
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        ops.gather_stats(x, wl, local, "mse", ste=ste, idx=idx, counts=counts, embed_sum=es, loss_partial=part, perm=perm)
+        sc = torch.empty(4, device=dev)
+        args = (counts, part, kl, n, float(n * d), 0.99, 1 - 0.99, 1e-5, k * 1e-5, 0.25, False)
+        ops.ema_cluster(cs, *args, 2, sc)
+        ops.ema_cluster(cs, *args, 3, sc)
+        ops.ema_embed(ew, wl, es, cs, 0.99, 1 - 0.99)
+        return keys
+
+    ts = []
+    with torch.no_grad():
+        for i in range(iters + 3):
+            cs.copy_(cs0), ew.copy_(ew0), wl.copy_(w)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            keys = call()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1))
+    med = statistics.median(ts)
+    out = {"name": "c5_shard", "workload": f"one code shard of C5: {kl} of {k} codes (code_offset {off}), N={n} tokens, "
+                                           "fwd + local-slice EMA, fine-grained entry points, no peer exchange",
+           "search": search, "regime": "uniform", "ms_per_call_median": med, "ms_per_call_min": min(ts),
+           "vectors_per_s": n / (med * 1e-3)}
+    if check:                                  # part of the CPU leg: the oracle as checker
+        from oracle import vq_oracle as vo
+        ns = 4096
+        idx_gpu = ((keys[:ns] & 0xFFFFFFFF) - off).cpu()
+        xs, wc = x[:ns].cpu(), w.cpu()
+        ref = torch.argmin(vo.distances(xs, wc), dim=1)
+        outside, inside = vo.classify_mismatches(xs, wc, idx_gpu, ref)
+        out["parity"] = {"tokens": ns, "idx_mismatch_outside_band": outside, "idx_mismatch_inside_band": inside,
+                         "against": "oracle argmin over the shard's code slice"}
+    out.update(roofline_fracs(n, kl, d, True, med))
+    return out
+
+
+def single_gpu_configs(args, dev):
+    """Every BASELINE configuration one GPU can hold besides the headline, plus the assignment regimes of c3."""
+    out = []
+    plan = [("c1", "uniform"), ("c2", "uniform"), ("c4", "uniform"), ("c3", "uniform"), ("c3", "cold"),
+            ("c3", "collapsed")]
+    for wl, regime in plan:
+        n, k, d, update, desc = WORKLOADS[wl]
+        state = build_state(wl, regime, 0, 1, dev)
+        w, ema_w, cs, x = state
+        mod = make_module(k, d, w, ema_w, cs, update, args.search, dev)
+        med, mn, res = per_call_ms(mod, x, w, ema_w, cs, args.config_iters)
+        entry = {"name": wl if regime == "uniform" else f"{wl}_{regime}", "workload": desc, "regime": regime,
+                 "search": args.search, "ms_per_call_median": med, "ms_per_call_min": mn,
+                 "vectors_per_s": n / (med * 1e-3), "codes_used": int(res[3].unique().numel())}
+        entry.update(roofline_fracs(n, k, d, update, med))
+        if not args.no_cpu_baseline:
+            leg = cpu_leg(k, d, update, args.search, state, dev, 2880 if wl == "c1" else 4096, 0.0, desc)
+            entry["parity"] = leg["parity"]
+            entry["cpu_ref_vectors_per_s_one_call"] = leg["value"]
+        out.append(entry)
+        del mod, state, w, ema_w, cs, x
+    out.append(c5_shard_config(dev, args.search, args.config_iters, not args.no_cpu_baseline))
+    return out
+
+
+# =====================================================================================================
+# ranks
+# =====================================================================================================
 def other_search(mod, x, w, ema_w, cs, args, n, k, d):
     """The same step with the other search mode (rank 0, single GPU): 'scan' = fused fp32 MFMA distance + argmin;
     'filter' = fp16 MFMA filter with a proven error bound + the scan's fp32 arithmetic on the surviving codes.
     Both produce the same indices (checked here on this batch, same initial state)."""
+    import torch
     from t5vqvae_amd import ops
     other = "filter" if args.search == "scan" else "scan"
     if other == "filter" and d % 64:
@@ -154,13 +364,6 @@ def other_search(mod, x, w, ema_w, cs, args, n, k, d):
             "pipe": "fp16 MFMA filter (2500 TF) + fp32 decision" if other == "filter" else "fp32 MFMA (157.3 TF)"}
 
 
-def step_bytes(n, k, d, update):
-    b = 4.0 * (n * d + k * d + n * d) + 8.0 * n + 4.0 * k
-    if update:
-        b += 4.0 * n * d + 12.0 * k * d + 12.0 * k
-    return b
-
-
 def measured_traffic(workload):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json; counters cannot be read from inside this process)."""
@@ -171,55 +374,177 @@ def measured_traffic(workload):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--regime", default="uniform", choices=["uniform", "cold"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--search", default="scan", choices=["scan", "filter", "auto"],
-                    help="how the module finds the nearest code for the headline number: 'scan' = the fused fp32 MFMA "
-                         "kernel (the north star's design, default); 'filter'/'auto' = fp16 filter + fp32 decision "
-                         "(identical indices); the other mode is always reported beside it")
-    args = ap.parse_args()
+def search_kernel_roofline(mod, x, n, k, d, args, workload):
+    """Roofline of the dominant kernel (fused distance + argmin), measured live with HIP events on the stream the
+    kernel runs on (torch's current stream is the one handed to the C ABI)."""
+    import torch
+    from t5vqvae_amd import ops
+    dev = x.device
+    flat = x.reshape(-1, d)
+    wq = mod._embedding.weight.detach()
+    xx, ee = ops.row_sqnorms(flat, wq)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    filt = args.search == "filter" or (args.search == "auto" and d % 64 == 0 and n * k >= mod.filter_min_work)
+    search = (lambda: ops.dist_argmin_filtered(flat, wq, xx, ee, keys=keys, exact_keys=False)) if filt \
+        else (lambda: ops.dist_argmin(flat, wq, xx, ee, keys=keys))
+    for _ in range(2):
+        search()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        search()
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    peak = PEAK_F16_MFMA_TFLOPS if filt else PEAK_FP32_MFMA_TFLOPS
+    kname = "filtered search: filter_f16_kernel + prep/collect/refine" if filt \
+        else "dist_mfma_v2_kernel (fused distance+argmin)"
+    flops = 2.0 * n * k * d
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "kernel_ms": k_ms, "flops_per_launch": flops,
+            "traffic": None if filt else measured_traffic(workload),
+            "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+            "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k}
 
+
+def run_c5(args, rank, world, dev, dist, barrier):
+    """Config 5: K = 65536 codes sharded K/G per rank, N = 65536 replicated tokens; global argmin, then the grouped
+    (disentangled) forms.  Both codebook exchanges are timed: kept + refreshed asynchronously after the update
+    ("prefetch", the default) and gathered inside every call ("sync")."""
+    import torch
+    from t5vqvae_amd import synth
+    from t5vqvae_amd.sharded import CodeShardedVectorQuantizerEMA
+    n, k, d = (512, 1024, 64) if args.dry_run else (C5_TOKENS, C5_CODES, 768)
+    kl = k // world
+    w_full = synth.normal((k, d), 1000, 0, device=dev)
+    x, _ = synth.clustered(n, w_full, 0.5, 2000)
+    x = x.view(64, n // 64, d)
+    cs_full = torch.full((k,), float(n) / k, device=dev)
+    full = {"_embedding.weight": w_full, "_ema_w": w_full * cs_full.unsqueeze(1), "_ema_cluster_size": cs_full}
+
+    def build(roles=None):
+        m = CodeShardedVectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=roles is not None).to(dev)
+        m.load_full_state_dict(full)
+        m.encodings = "indices"
+        m.search = args.search
+        return m.train()
+
+    def timed(m, srl, steps, warmup):
+        with torch.no_grad():
+            for _ in range(warmup):
+                m(x, srl)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m(x, srl)
+            barrier()
+            el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t)
+        return el / steps * 1e3
+
+    mod = build()
+    ms = timed(mod, None, args.steps, args.warmup)
+    mod.exchange = "sync"
+    ms_sync = timed(mod, None, max(3, args.steps // 2), 2)
+    grouped = {}
+    role_sets = {"8_roles_aligned_to_shards": [(i * (k // 8), (i + 1) * (k // 8)) for i in range(8)],
+                 "5_unequal_roles_straddling_shards": [(0, k // 10), (k // 10, k // 3), (k // 3, k // 2 + 5),
+                                                       (k // 2 + 5, k - k // 7), (k - k // 7, k)]}
+    for name, roles in role_sets.items():
+        m = build(roles)
+        srl = synth.role_ranges(n, roles, 77, 0, device=dev).view(64, n // 64, 2)
+        g_ms = timed(m, srl, max(3, args.steps // 2), 2)
+        flops = 2.0 * d * sum(float((srl.view(-1, 2)[:, 0] == a).sum()) * (b - a) for a, b in roles)
+        grouped[name] = {"ms_per_step": g_ms, "vectors_per_s": n / (g_ms * 1e-3), "algorithmic_flops": flops,
+                         "frac_of_mfma_roofline": flops / (PEAK_FP32_MFMA_TFLOPS * 1e12 * world) / (g_ms * 1e-3)}
+        del m
+    if rank != 0:
+        return None
+    flops = 2.0 * n * k * d
+    return {"metric": "quantized vectors/sec (fwd+EMA)", "value": n / (ms * 1e-3), "unit": "vectors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5 K={k} code-sharded {kl} codes/GPU, N={n} replicated tokens, D={d}, fwd+EMA",
+                       "K": k, "codes_per_gpu": kl, "tokens": n, "D": d, "regime": "uniform", "search": args.search,
+                       "parallelism": f"code-sharded x{world}",
+                       "exchange": "all-reduce(MIN) of packed int64 keys [N]; gathered codebook kept and refreshed "
+                                   "asynchronously after the update; 2-scalar all-reduce"},
+            "step_frac_of_mfma_roofline": flops / (PEAK_FP32_MFMA_TFLOPS * 1e12 * world) / (ms * 1e-3),
+            "codebook_exchange": {"prefetch_ms_per_step": ms, "sync_allgather_ms_per_step": ms_sync,
+                                  "allgather_bytes": 4.0 * k * d},
+            "grouped": grouped, "roofline": None, "cpu_baseline": None}
+
+
+def run_rank(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus and "RANK" in os.environ:
+        args.gpus = world                      # under a launcher the launcher's world size is the truth
+    dry = args.dry_run
+    if dry:                                    # CPU rehearsal of the launch / rendezvous / all-reduce path
+        dev = torch.device("cpu")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fake_ops
+        from t5vqvae_amd import vqvae
+        vqvae.ops = fake_ops
+        torch.cuda.synchronize = lambda *a, **kw: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     # T5VQ_BENCH_FORCE_DIST=1 takes the RCCL path even at world size 1 (rehearsal on a one-GPU box)
     use_dist = world > 1 or os.environ.get("T5VQ_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from t5vqvae_amd import VectorQuantizerEMA, ops
-    from t5vqvae_amd.sharded import shard_tokens
-    n, k, d, update, desc = WORKLOADS[args.workload]
-    w, ema_w, cs, x = build_state(args.workload, args.regime, rank, world, dev)
-    mod = VectorQuantizerEMA(k, d, 0.25, decay=0.99).to(dev)
-    with torch.no_grad():
-        mod._embedding.weight.copy_(w)
-        mod._ema_w.copy_(ema_w)
-        mod._ema_cluster_size.copy_(cs)
-    mod.encodings = "indices"
-    mod.search = args.search
-    mod.train(update)
-    if use_dist:
-        shard_tokens(mod)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "c3" if args.gpus == 1 else "c4"
+    if workload == "c5":
+        if not use_dist:
+            raise SystemExit("--workload c5 is the code-sharded form: run it with --gpus N > 1 "
+                             "(or T5VQ_BENCH_FORCE_DIST=1 for a one-rank rehearsal)")
+        result = run_c5(args, rank, world, dev, dist, barrier)
+        if rank == 0:
+            result["rccl_world_size"] = dist.get_world_size()
+            result["dry_run"] = dry
+            print(json.dumps(result), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if workload in ("c1", "c2") and world > 1:
+        raise SystemExit(f"--workload {workload} is a single-GPU configuration")
+
+    from t5vqvae_amd.sharded import shard_tokens
+    n, k, d, update, desc = WORKLOADS[workload]
+    strong = workload == "c4" and use_dist
+    if strong:                                 # config 4 as written: 2^20 tokens in total, N/G per rank
+        n = C4_TOTAL_TOKENS // world
+        desc = f"C4 N=2^20 tokens in total ({n}/GPU) K=16384 D=768 token-sharded fused fwd+EMA"
+    if dry:
+        n, k, d = 256, 128, 64
+        WORKLOADS[workload] = (n, k, d, update, desc)
+    w, ema_w, cs, x = build_state(workload, args.regime, rank, world, dev, n=n, k=k)
+    mod = make_module(k, d, w, ema_w, cs, update, args.search, dev)
+    if use_dist:
+        shard_tokens(mod)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -237,64 +562,105 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world * args.steps / elapsed
 
+    dist_info = None
+    if use_dist:
+        # the exchange step alone: K all-reduces of the statistics head [embed_sum | counts | loss_sum]
+        buf = torch.zeros(k * d + k + 1, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dist.all_reduce(buf)
+        barrier()
+        ar = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        dist_info = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "allreduce_ms_per_step": float(ar) / args.steps * 1e3, "allreduce_bytes": 4.0 * (k * d + k + 1)}
+        if strong and world > 1 and not dry:
+            # the SAME workload on one GPU (rank 0 alone, the others wait): the reference point of strong scaling
+            if rank == 0:
+                w1, e1_, c1_, x1 = build_state("c4", args.regime, 0, 1, dev, n=C4_TOTAL_TOKENS, k=k)
+                m1 = make_module(k, d, w1, e1_, c1_, update, args.search, dev)
+                with torch.no_grad():
+                    m1(x1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        m1(x1)
+                    torch.cuda.synchronize()
+                    one_ms = (time.perf_counter() - t0) / 3 * 1e3
+                del m1, w1, e1_, c1_, x1
+                one = C4_TOTAL_TOKENS / (one_ms * 1e-3)
+                dist_info["single_gpu_same_workload"] = {"ms_per_step": one_ms, "value": one, "unit": "vectors/s",
+                                                         "steps": 3}
+                dist_info["speedup_vs_single_gpu"] = value / one
+                dist_info["parallel_efficiency_vs_single_gpu"] = value / one / world
+            dist.barrier()
+
     result = None
     if rank == 0:
-        # roofline of the dominant kernel (fused distance + argmin), measured live with HIP events on the
-        # stream the kernel runs on (torch's current stream is the one handed to the C ABI)
-        flat = x.reshape(-1, d)
-        wq = mod._embedding.weight.detach()
-        xx, ee = ops.row_sqnorms(flat, wq)
-        keys = torch.empty(n, dtype=torch.int64, device=dev)
-        filt = args.search == "filter" or (args.search == "auto" and d % 64 == 0 and n * k >= mod.filter_min_work)
-        search = (lambda: ops.dist_argmin_filtered(flat, wq, xx, ee, keys=keys, exact_keys=False)) if filt \
-            else (lambda: ops.dist_argmin(flat, wq, xx, ee, keys=keys))
-        for _ in range(2):
-            search()
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            search()
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / reps
-        peak = PEAK_F16_MFMA_TFLOPS if filt else PEAK_FP32_MFMA_TFLOPS
-        kname = "filtered search: filter_f16_kernel + prep/collect/refine" if filt \
-            else "dist_mfma_v2_kernel (fused distance+argmin)"
         flops = 2.0 * n * k * d
-        achieved = flops / (k_ms * 1e-3) / 1e12
         result = {
             "metric": "quantized vectors/sec (fwd+EMA)" if update else "quantized vectors/sec (fwd)",
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "D": d,
-                       "regime": args.regime, "parallelism": f"token-sharded x{world}" if world > 1 else "single GPU",
+                       "regime": args.regime, "search": args.search,
+                       "parallelism": f"token-sharded x{world}" if use_dist else "single GPU",
                        "encodings": "indices (dense one-hot excluded, SURVEY 8b)"},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "kernel_ms": k_ms,
-                         "flops_per_launch": flops, "traffic": None if filt else measured_traffic(args.workload),
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-                         "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k},
+            "roofline": None if dry else search_kernel_roofline(mod, x, n, k, d, args, workload),
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
-            # SURVEY 8d algorithmic bytes of the whole step (fwd: x, W, q, idx, ee; EMA: x again, ema_w r/w, W w)
             "step_algorithmic_bytes": step_bytes(n, k, d, update),
             "step_frac_of_hbm_roofline": step_bytes(n, k, d, update) / (PEAK_HBM_GBS * 1e9) / (ms_per_step * 1e-3),
+            "dry_run": dry,
         }
-    if rank == 0 and world == 1:
-        result["config"]["search"] = args.search
+        if dist_info:
+            result.update(dist_info)
+    if rank == 0 and world == 1 and not dry:
+        med, mn, _ = per_call_ms(mod, x, w, ema_w, cs, args.config_iters)
+        result["per_call"] = {"ms_median": med, "ms_min": mn, "protocol": "HIP events around one call, state reset "
+                              "outside the timed region", "frac_of_mfma_roofline":
+                              (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (med * 1e-3)}
         result["other_search"] = other_search(mod, x, w, ema_w, cs, args, n, k, d)
     if use_dist:
         dist.barrier()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.workload, dev)
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            result["cpu_baseline"] = cpu_leg(k, d, update, args.search, (w, ema_w, cs, x), dev, 8192, 20.0, desc)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
+        if world == 1 and not dry and not args.no_configs and not use_dist:
+            del mod
+            result["configs"] = single_gpu_configs(args, dev)
+        print(json.dumps(result), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"],
+                    help="auto: c3 on one GPU (BASELINE config 3, the headline), c4 strong scaling on several")
+    ap.add_argument("--regime", default="uniform", choices=["uniform", "cold", "collapsed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration table of the one-GPU run")
+    ap.add_argument("--config-iters", type=int, default=10)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU + gloo + a test stand-in for the kernels: exercises the launcher and the collectives only")
+    ap.add_argument("--search", default="scan", choices=["scan", "filter", "auto"],
+                    help="how the module finds the nearest code for the headline number: 'scan' = the fused fp32 MFMA "
+                         "kernel (the north star's design, default); 'filter'/'auto' = fp16 filter + fp32 decision "
+                         "(identical indices); the other mode is always reported beside it")
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,11 @@ Code sharding (BASELINE config 5) -- ``CodeShardedVectorQuantizerEMA``.
       1. all-reduce(min) of the packed int64 (distance, global index) keys [N] -- RCCL has no MINLOC; min of
          the packed key is "lowest distance, then lowest index" = torch.argmin's tie rule across shards;
       2. all-gather of the codebook slices [K, D] so the winning rows can be gathered locally (the
-         disentangled mode's slice-relative indices may point into ANY shard, vqvae/vqvae.py:116-119);
+         disentangled mode's slice-relative indices may point into ANY shard, vqvae/vqvae.py:116-119).  The
+         gathered codebook is KEPT: it is refreshed only when a slice changed -- in evaluation never, in
+         training right after the EMA update, asynchronously (``exchange = "prefetch"``: the 201 MB of C5 move
+         on RCCL's stream while the next call's distance search runs, and are waited for only before that
+         call's row gather).  ``exchange = "sync"`` gathers inside every call (the round-1 behaviour);
       3. all-reduce(sum) of two scalars: the Laplace normaliser sum(cluster_size) and the perplexity's
          entropy partial sum.
     EMA statistics need no reduction: tokens are replicated, so each rank accumulates counts / embed_sum for
@@ -81,6 +85,8 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         self._epsilon = epsilon
         self.disentanglement = disentanglement
         self.loss = loss
+        self.exchange = "prefetch"       # "prefetch" | "sync": when the gathered codebook is refreshed (module docstring)
+        self._full = None                # (gathered codebook [K, D], local data_ptr, local _version, pending work | None)
 
     # --- state in the reference's (unsharded) layout -------------------------------------------------
     @torch.no_grad()
@@ -103,9 +109,33 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         return out
 
     def _full_codebook(self, w_local):
-        full = torch.empty(self._num_embeddings, self._embedding_dim, dtype=w_local.dtype, device=w_local.device)
+        """The whole codebook [K, D] on this rank.  Kept between calls while the local slice is unchanged (pointer and
+        version of the Parameter, as for the code norms; every rank takes the same decision because every rank's
+        slice changes in the same calls); a refresh started by ``_refresh_full_codebook`` is waited for here, on the
+        stream (no host wait)."""
+        param = self._embedding.weight
+        ent = self._full
+        if (self.exchange == "prefetch" and ent is not None and ent[1] == param.data_ptr()
+                and ent[2] == param._version and ent[0].device == w_local.device):
+            if ent[3] is not None:
+                ent[3].wait()                    # current stream waits for RCCL's stream
+                self._full = (ent[0], ent[1], ent[2], None)
+            return ent[0]
+        full = ent[0] if (ent is not None and ent[0].device == w_local.device) else \
+            torch.empty(self._num_embeddings, self._embedding_dim, dtype=w_local.dtype, device=w_local.device)
         dist.all_gather_into_tensor(full, w_local.contiguous(), group=self.group)
+        self._full = (full, param.data_ptr(), param._version, None)
         return full
+
+    def _refresh_full_codebook(self):
+        """After the EMA update of the local slice: start the all-gather of the new slices into the kept buffer
+        (in place: the collective is ordered after this call's row gather, which was the buffer's last reader) and
+        return at once; the next ``_full_codebook`` waits for it."""
+        ent = self._full
+        if self.exchange != "prefetch" or ent is None:
+            return
+        work = dist.all_gather_into_tensor(ent[0], self._embedding.weight.data, group=self.group, async_op=True)
+        self._full = (ent[0], ent[1], ent[2], work)
 
     def _global_keys(self, x, w_local, ranges):
         keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin)
@@ -129,7 +159,6 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         perm = (ops.order_by_code(keys, w_full.shape[0])
                 if (embed_sum is not None and n >= ops.ORDER_MIN_TOKENS) else None)
         partial = torch.empty(n if perm is not None else ops.gather_blocks(n), dtype=torch.float32, device=dev)
-        loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         ste = torch.empty_like(x)
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         diff = torch.empty_like(x) if want_diff else None
@@ -137,12 +166,12 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         ops.gather_stats(x, w_full, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx, counts=counts,
                          embed_sum=embed_sum, loss_partial=partial, stats_begin=self.code_begin, stats_count=kl,
                          perm=perm)
-        ops.reduce_partials(partial, loss_sum)       # tokens are replicated: the loss needs no reduction
+        # tokens are replicated: the loss needs no reduction across ranks, and the cluster kernel adds the terms up
 
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
         denom = float(n * d) if mse else float(plan.batch)
         cs = self._ema_cluster_size if update else None
-        args = (counts, loss_sum, kl, n, denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, False)
+        args = (counts, partial, kl, n, denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, False)
         ops.ema_cluster(cs, *args, 2, scalars)                                   # local partial sums
         dist.all_reduce(scalars[1:3], op=dist.ReduceOp.SUM, group=self.group)    # entropy, sum(cluster_size)
         ops.ema_cluster(cs, *args, 3, scalars)                                   # smoothing + perplexity
@@ -154,6 +183,8 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         elif update:
             ops.ema_embed(self._ema_w.data, self._embedding.weight.data, embed_sum, self._ema_cluster_size,
                           plan.decay, 1 - plan.decay)
+        if update:
+            self._refresh_full_codebook()
         self._last_scalars = scalars
         return {"loss": vqvae._scalar_of(scalars, 0), "ppl": vqvae._scalar_of(scalars, 1), "ste": ste, "idx": idx,
                 "diff": diff, "q": q, "dims": (n, d, k, plan.batch)}
