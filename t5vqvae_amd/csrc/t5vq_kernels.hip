@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_kernel(
     if (again) __syncthreads();   // the previous pass's LDS reads are done before this pass restages
     again = true;
     const int grp = vb / (8 * n_splits);
-    const int split = (vb / 8) % n_splits;
+    int split = (vb / 8) % n_splits;
+    if (RANGED && !LISTED) split = (split + grp) % n_splits;   // as in dist_mfma_v2_kernel
     const int tok_base = (grp * 8 + (vb & 7)) * TOK_TILE;
     if (tok_base >= N) continue;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
@@ -501,14 +502,20 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     // Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness): the n_splits
     // workgroups of one token tile are given ids 8 apart so that their X tile is fetched into ONE L2.
     const int grp = blockIdx.x / (8 * n_splits);
-    const int split = (blockIdx.x / 8) % n_splits;
+    int split = (blockIdx.x / 8) % n_splits;
+    // RANGED: role-bucketed batches leave ONE split with work for long runs of token tiles.  Unswizzled, those
+    // workgroups' ids inside an XCD would all share one residue mod n_splits and the dispatcher, which deals
+    // consecutive workgroups round the XCD's shader arrays, would send them all to the same quarter of the CUs
+    // (measured: one role of 1024 codes out of 8192 at N = 65536 took 3.0 ms against 0.72 ms of matrix work).
+    // Rotating the split by the token group spreads them; which workgroup takes which split is free.
+    if (RANGED) split = (split + grp) % n_splits;
     const int tok_base = (grp * 8 + (blockIdx.x & 7)) * TOK_TILE;
     if (tok_base >= N) return;
     const int n_code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
-    if (tile_end <= tile_begin) return;
+    if (!RANGED && tile_end <= tile_begin) return;   // RANGED: the split's share is cut from the token tile's own range below
     const int n_chunks = D / BKC;
 
     const int s_row = tid / C::F4_PER_ROW;
@@ -528,10 +535,17 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     }
     gptr_t wpc[C::WV];
     gptr_t wpn[C::WV];
+    // RANGED: workgroup-relative tile ct is code tile tile_begin + (ct + rot) % n_tiles (rot set below); plain: rot = 0
+    int rot = 0, n_tiles_rot = 1 << 30;
+    auto tile_at = [&](int ct) {
+        int t = ct + rot;
+        if (RANGED && t >= n_tiles_rot) t -= n_tiles_rot;
+        return tile_begin + t;
+    };
     auto set_wptrs = [&](gptr_t (&wp)[C::WV], int ct) {
 #pragma unroll
         for (int j = 0; j < C::WV; ++j) {
-            int c = (tile_begin + ct) * CODE_TILE + s_row + C::ROWS_PER_PASS * j;
+            int c = tile_at(ct) * CODE_TILE + s_row + C::ROWS_PER_PASS * j;
             if (c > K - 1) c = K - 1;
             wp[j] = wg + static_cast<size_t>(c) * D + s_col;
         }
@@ -564,14 +578,28 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
         tlo = min(min(red[0], red[2]), min(red[4], red[6]));
         thi = max(max(red[1], red[3]), max(red[5], red[7]));
         __syncthreads();   // red is overwritten by the prologue below
-        tile_begin = max(tile_begin, tlo);
-        tile_end = min(tile_end, thi);
-        if (tile_end <= tile_begin) {   // workgroup-uniform: nothing admissible in this split
+        // The n_splits workgroups of this token tile divide ITS admissible code tiles [tlo, thi) among themselves
+        // (not the whole codebook): with role-bucketed tokens every workgroup of the grid then has an equal share of
+        // real work, whatever the role layout.  (Splitting the codebook statically left 7 of 8 workgroups idle at 8
+        // roles and the busy ones unevenly spread over the CUs: 1.34 ms against 0.72 ms of matrix work.)
+        const int per = (max(thi - tlo, 0) + n_splits - 1) / n_splits;
+        tile_begin = tlo + split * per;
+        tile_end = min(tile_begin + per, thi);
+        if (tile_end <= tile_begin) {   // workgroup-uniform: nothing admissible for this workgroup
             if (!atomic_merge && h == 0 && tok < N) keys[tok] = KEY_NONE;
             return;
         }
     }
     const int n_tiles = tile_end - tile_begin;
+    if (RANGED) {
+        // Role-bucketed batches put tokens of ONE role into all the token tiles an XCD holds at a time; walking the
+        // role's code tiles in the same order, 64 workgroups would ask one L2 channel for the same lines at the same
+        // moment (measured: 8 roles of 1024 codes at N = 65536, 1.45 ms against 0.72 ms of matrix work).  Each token
+        // tile therefore starts at its own code tile and wraps around; ties are resolved by code id, not by visiting
+        // order (below), so the keys do not change.
+        n_tiles_rot = n_tiles;
+        rot = (tok_base / TOK_TILE) % n_tiles;
+    }
     float best = __int_as_float(0x7F800000);
     int best_code = RANGED ? CODE_NONE : tile_begin * CODE_TILE;
 
@@ -709,7 +737,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
 #pragma unroll
         for (int j = 0; j < C::WV; ++j) wpc[j] = wpn[j];
 
-        const int code0 = (tile_begin + ct) * CODE_TILE + 4 * h;
+        const int code0 = tile_at(ct) * CODE_TILE + 4 * h;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -724,7 +752,9 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
                     if (RANGED) {
                         const long long gc = code_offset + code;
                         const bool valid = gc >= r_start && gc < r_end && code < K;
-                        if (valid && (d < best || best_code == CODE_NONE)) {
+                        // first admissible code always taken; equal distances: the lower code wins whatever the
+                        // order in which the tiles are visited
+                        if (valid && (d < best || best_code == CODE_NONE || (d == best && code < best_code))) {
                             best = d;
                             best_code = code;
                         }
@@ -1664,7 +1694,10 @@ using Cfg15 = DistCfg<4, 32, false, 2, 5>;
 //     XCD, ~2.5 MB of L2 left for X tiles).  Measured at C3 (rocprofv3 FETCH_SIZE x 2): 12.9 GB unsplit ->
 //     4.7 GB at 8 splits, kernel time -1 %.
 // Returns the number of splits; *time_out = modelled time in units of one 128-code tile on one pipe.
-int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time_out) {
+// ranged: the splits divide each token tile's OWN admissible code range (dist_mfma_v2_kernel), so more splits mean
+// finer, better balanced pieces whatever the role layout -- among the choices within 2 % of the best modelled time
+// the LARGEST number of splits is taken (8 roles of 1024 codes at N = 65536: 0.96 -> 0.81 ms).
+int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time_out, bool ranged = false) {
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + code_tile - 1) / code_tile;
     const double tile_cost = code_tile / 128.0;
@@ -1683,6 +1716,10 @@ int64_t plan_splits(int64_t N, int64_t K, int64_t D, int code_tile, double* time
                 continue;
             }
             if (time > best_time * 1.02) continue;
+            if (ranged) {
+                if (s > splits) splits = s;
+                continue;
+            }
             const double tiles_per_xcd = s >= 64 ? 1.0 : 64.0 / static_cast<double>(s);
             const double x_ws = tiles_per_xcd * TOK_TILE * static_cast<double>(D) * 4.0;
             const double miss = x_ws > 2.5e6 ? 1.0 - 2.5e6 / x_ws : 0.0;
@@ -1746,7 +1783,7 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
     int64_t splits = 1;
     if (!dist) {
-        splits = plan_splits(N, K, D, C::CODE_TILE, nullptr);
+        splits = plan_splits(N, K, D, C::CODE_TILE, nullptr, range != nullptr && !opts.bounded && V2);
         if (g_force_splits > 0) {
             splits = g_force_splits;
             while (splits > code_tiles) splits /= 2;
