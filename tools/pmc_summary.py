@@ -12,7 +12,8 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         name = r["Kernel_Name"]
         if "anonymous namespace" not in name or "elementwise_kernel_with_index" in name:
             continue
-        short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+        short = name.split("(anonymous namespace)::", 1)[-1].split("(float", 1)[0].split("(long", 1)[0]
+        short = short.replace("(anonymous namespace)::", "")
         per[(short, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (short, _, c), v in per.items():
         acc[short][c].append(v)
