@@ -92,6 +92,94 @@ def test_training_loop_and_checkpoint(variant):
     assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
+@pytest.mark.parametrize("variant", ["ema", "plain", "ema_roles"])
+def test_harness_steps_replayed_through_the_oracle(variant):
+    """The first training steps of the harness, replayed through the CPU oracle: the encoder output that enters the
+    VQ at each step (t5/load_t5.py:518) is captured together with the gradient the decoder sends back into the
+    quantized tensor; the oracle's faithful module (tests/oracle_module.py) starts from the same pre-step state, takes
+    the same input and the same incoming gradient, and must give the same loss, indices (band rule), quantized
+    tensor, gradient w.r.t. the VQ input (train_t5.py:56-61: loss = CE + recon_loss, backward), codebook gradient
+    (plain variant) and EMA buffers (EMA variants) -- all at <= 1e-5."""
+    from oracle import vq_oracle as vo
+    from oracle_module import OracleQuantizer
+    from t5vqvae_amd import VectorQuantizer, VectorQuantizerEMA
+    k, d = 1000, 768
+    roles = {"V": (0, 300), "residual": (300, k)} if variant == "ema_roles" else {}
+    ema = variant != "plain"
+    if ema:
+        vq = VectorQuantizerEMA(k, d, 0.25, decay=0.99, disentanglement=bool(roles), loss="mse", **roles)
+    else:
+        vq = VectorQuantizer(k, d, 0.25, decay=0.99, loss="mse")
+    vq.encodings = "indices"
+    model = T5AE(build_t5(), vq).cuda()
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(1, 384, (8, 26), generator=g).cuda()
+    srl = None
+    if roles:
+        pick = torch.randint(0, 2, (8, 26), generator=g)
+        srl = torch.tensor([roles["V"], roles["residual"]])[pick].cuda()
+
+    cap = {}
+
+    def pre_hook(mod, args):
+        cap["x"] = args[0].detach().cpu().clone()
+        args[0].register_hook(lambda gr: cap.__setitem__("gx", gr.detach().cpu().clone()))
+
+    def post_hook(mod, args, out):
+        cap["loss"], cap["q"] = out[0].detach().cpu().clone(), out[1].detach().cpu().clone()
+        cap["idx"] = out[3].detach().view(-1).cpu().clone()
+        out[1].register_hook(lambda gr: cap.__setitem__("gq", gr.detach().cpu().clone()))
+
+    vq.register_forward_pre_hook(pre_hook)
+    vq.register_forward_hook(post_hook)
+
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        den = float(b.norm())
+        return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+    compared = 0
+    for step in range(5):
+        before = {n: t.detach().cpu().clone() for n, t in vq.state_dict().items()}
+        ce, recon, ppl = model(ids, ids, srl)
+        (ce + recon).backward()                                                     # train_t5.py:56,61
+        gw = None if ema else vq._embedding.weight.grad.detach().cpu().clone()
+        after = {n: t.detach().cpu().clone() for n, t in vq.state_dict().items()}   # EMA buffers moved in the forward
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+
+        ref = OracleQuantizer("VectorQuantizerEMA" if ema else "VectorQuantizer", num_embeddings=k, embedding_dim=d,
+                              commitment_cost=0.25, decay=0.99, disentanglement=bool(roles), loss="mse")
+        ref.load_state_dict(before)
+        ref.train()
+        xr = cap["x"].clone().requires_grad_(True)
+        srl_c = None if srl is None else srl.cpu()
+        lo, qr, pr, enc = ref(xr, srl_c)
+        ((lo + (qr * cap["gq"]).sum())).backward()          # the decoder's gradient into quantized, + d(recon_loss) = 1
+        idx_ref = enc.argmax(1)
+        outside, inside = vo.classify_mismatches(cap["x"].view(-1, d), before["_embedding.weight"], cap["idx"], idx_ref,
+                                                 srl_c.view(-1, 2) if srl_c is not None else None)
+        assert outside == 0, f"step {step}: {outside} index mismatches outside the near-tie band"
+        if inside:
+            continue                 # a near-tie resolved the other way: every downstream tensor legitimately differs
+        tol = 1e-5
+        compared += 1
+        assert rel(cap["loss"], lo.detach()) <= tol, (step, "loss")
+        assert rel(cap["q"], qr.detach()) <= tol, (step, "quantized")
+        assert rel(ppl, pr.detach()) <= tol, (step, "perplexity")
+        assert rel(cap["gx"], xr.grad) <= tol, (step, "gradient w.r.t. the VQ input")
+        if ema:
+            st = ref.state_dict()
+            for name in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
+                assert rel(after[name], st[name]) <= tol, (step, name)
+        else:
+            assert rel(gw, ref._embedding.weight.grad) <= tol, (step, "codebook gradient")
+    assert compared >= 3, f"only {compared} of 5 steps were free of near-ties"
+
+
 def test_mid_encoder_call_site_returns_pair():
     """modeling_t5.py:847-856 calls vqvae(hidden_states, srl) inside the encoder and keeps [0] and [1] only."""
     from t5vqvae_amd import VectorQuantizerEMA
