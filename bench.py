@@ -409,6 +409,35 @@ def search_kernel_roofline(mod, x, n, k, d, args, workload):
             "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k}
 
 
+def series_point(workload, n, k, d, args, rank, world, dev, dist, barrier, steps):
+    """A second token-sharded measurement inside the same run (same protocol as the headline: warm-up, K steps
+    between barriers, MAX over ranks), so that every line carries a point of BOTH multi-GPU series: config 3 weak
+    (65536 tokens per GPU, K = 8192) and config 4 strong (2^20 tokens in total, K = 16384)."""
+    import torch
+    from t5vqvae_amd.sharded import shard_tokens
+    w, ema_w, cs, x = build_state(workload, args.regime, rank, world, dev, n=n, k=k)
+    mod = make_module(k, d, w, ema_w, cs, True, args.search, dev)
+    if dist is not None:
+        shard_tokens(mod)
+    with torch.no_grad():
+        for _ in range(2):
+            mod(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mod(x)
+        barrier()
+        el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    ms = el / steps * 1e3
+    return {"n_gpus": world, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "steps": steps, "ms_per_step": ms,
+            "value": n * world / (ms * 1e-3), "unit": "vectors/s",
+            "step_frac_of_mfma_roofline": (2.0 * n * k * d / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms * 1e-3)}
+
+
 def run_c5(args, rank, world, dev, dist, barrier):
     """Config 5: K = 65536 codes sharded K/G per rank, N = 65536 replicated tokens; global argmin, then the grouped
     (disentangled) forms.  Both codebook exchanges are timed: kept + refreshed asynchronously after the update
@@ -618,6 +647,21 @@ def run_rank(args):
         }
         if dist_info:
             result.update(dist_info)
+    # Both multi-GPU series in every line of a default (--workload auto) run: the one-GPU line adds the config-4 point
+    # (the whole 2^20 tokens on one GPU), the N-GPU lines add the config-3 weak point -- a reader (or the driver) can then
+    # compare like with like across N whichever of the two it follows.
+    series = None
+    if args.workload == "auto" and not dry:
+        if world == 1 and not use_dist:
+            series = {"c4_strong": series_point("c4", C4_TOTAL_TOKENS, 16384, d, args, 0, 1, dev, None, barrier, 3)}
+        elif use_dist:
+            series = {"c3_weak": series_point("c3", 65536, 8192, d, args, rank, world, dev, dist, barrier,
+                                              args.steps)}
+    if rank == 0 and series:
+        result["series"] = series
+        result["series_note"] = ("config 3 (this line's headline at --gpus 1) scales WEAKLY: 65536 tokens per GPU; "
+                                 "config 4 (the headline at --gpus N > 1) scales STRONGLY: 2^20 tokens in total. "
+                                 "Compare c3 points with c3 points and c4 points with c4 points across N.")
     if rank == 0 and world == 1 and not dry:
         med, mn, _ = per_call_ms(mod, x, w, ema_w, cs, args.config_iters)
         result["per_call"] = {"ms_median": med, "ms_min": mn, "protocol": "HIP events around one call, state reset "
