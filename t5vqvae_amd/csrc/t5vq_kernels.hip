@@ -483,15 +483,42 @@ __device__ __forceinline__ void sgb_spread_reads() {
     }
 }
 
-template <class C, bool RANGED, bool D2>
+// SELF (small problems, where a launch costs as much as the work it carries): the kernel needs no launch before it.
+//  * |x|^2 is taken from the X tile as it is staged for the first code tile, in row_sqnorm_wave's lane layout and
+//    order -- K0's lane l holds float4 #(l + 64 j); the staging thread (row, c) sees float4 #(8 kc + c) in chunk kc,
+//    i.e. K0 lane 8 (kc % 8) + c, so it keeps 8 accumulators per row (one per kc % 8, hence D % 256 == 0 and the
+//    chunk loop unrolled by 8) and the xor butterfly runs first over those 8 (lane bits 5..3), then over the 8
+//    threads of the row (lane bits 2..0): bit-identical to t5vq_row_sqnorms_f32.
+//  * the code splits of a token tile do not merge into one prefilled key with atomicMin: split s writes its key to
+//    keys[s * N + token] and the consumer (gather_stats_kernel) takes the minimum of the n_splits slots;
+//  * the statistics buffers the following kernels add into are zeroed here, a slice per workgroup.
+struct SelfArgs {
+    float* zero[2];        // counts, embed_sum (16-byte aligned or null)
+    long long nz[2];       // lengths in floats
+};
+
+template <class C, bool RANGED, bool D2, bool SELF = false>
 __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
     const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
-    int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys) {
+    int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys,
+    SelfArgs self = SelfArgs{}) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE, G = C::G;
     constexpr int NLD = C::XV + C::WV;
     static_assert(G >= 2 && NLD < 4 * NT, "interleave plan needs room");
+    static_assert(!SELF || (D2 && !RANGED && BKC == 32 && C::F4_PER_ROW == 8), "SELF: plain search, staged two ahead");
+    if (SELF) {   // every workgroup of the grid zeroes its slice of the statistics (before any early return)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long n4 = self.nz[r] >> 2;   // lengths are multiples of 4 floats (checked on the host)
+            const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+            const long long lo = per * blockIdx.x;
+            const long long hi = lo + per < n4 ? lo + per : n4;
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) reinterpret_cast<f32x4*>(self.zero[r])[i] = z;
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -515,7 +542,13 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     int tile_begin = split * tiles_per_split;
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > n_code_tiles) tile_end = n_code_tiles;
-    if (!RANGED && tile_end <= tile_begin) return;   // RANGED: the split's share is cut from the token tile's own range below
+    if (!RANGED && tile_end <= tile_begin) {   // RANGED: the split's share is cut from the token tile's own range below
+        if (SELF) {                            // an empty split still owns a key slot per token
+            const int t = tok_base + (tid & 127);
+            if (tid < TOK_TILE && t < N) keys[static_cast<size_t>(split) * N + t] = KEY_NONE;
+        }
+        return;
+    }
     const int n_chunks = D / BKC;
 
     const int s_row = tid / C::F4_PER_ROW;
@@ -554,7 +587,14 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
 
     const int tok = tok_base + wave * 32 + l31;
     const int tok_c = tok < N ? tok : N - 1;
-    const float xv = xx[tok_c];
+    float xv = (SELF && !xx) ? 0.f : xx[tok_c];   // SELF without given norms: set after the first code tile
+    float xacc[SELF ? C::XV : 1][SELF ? 8 : 1];    // SELF: |x|^2 accumulators, [staged row j][chunk index mod 8]
+    if (SELF) {
+#pragma unroll
+        for (int j = 0; j < C::XV; ++j)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) xacc[j][m] = 0.f;
+    }
     long long r_start = 0, r_end = 0;
     if (RANGED) {
         r_start = range[2 * static_cast<size_t>(tok_c)];
@@ -606,8 +646,11 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     set_wptrs(wpc, 0);
     {   // prologue: chunk 0 of tile 0 into buffer 0
 #pragma unroll
-        for (int j = 0; j < C::XV; ++j)
-            *reinterpret_cast<f32x4*>(lds + st_off + C::ROWS_PER_PASS * ROW * j) = *(gvec_t)(xp[j]);
+        for (int j = 0; j < C::XV; ++j) {
+            const f32x4 v = *(gvec_t)(xp[j]);
+            *reinterpret_cast<f32x4*>(lds + st_off + C::ROWS_PER_PASS * ROW * j) = v;
+            if (SELF) xacc[j][0] = sq4(v, xacc[j][0]);
+        }
 #pragma unroll
         for (int j = 0; j < C::WV; ++j)
             *reinterpret_cast<f32x4*>(lds + C::X_IMG + st_off + C::ROWS_PER_PASS * ROW * j) =
@@ -629,8 +672,10 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
 
     // One chunk: MFMAs on buffer `buf`, staging of the next chunk (source pointers wp, column koff) into buf^1.
     // P = parity of the chunk (D2 only): loads go to stg[P], the ds_writes drain stg[P ^ 1].
-    auto body = [&](const gptr_t (&wp)[C::WV], int koff, auto parity) {
+    using NoAcc = std::integral_constant<int, -1>;
+    auto body = [&](const gptr_t (&wp)[C::WV], int koff, auto parity, auto accm) {
         constexpr int P = decltype(parity)::value;
+        constexpr int AM = decltype(accm)::value;
         const float* xs = lds + buf * C::STAGE + rd_x;
         const float* ws = lds + buf * C::STAGE + rd_w;
         float* dst = lds + (buf ^ 1) * C::STAGE + st_off;
@@ -666,8 +711,10 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
         }
         if (C::ABL != 4) {
 #pragma unroll
-            for (int j = 0; j < C::XV; ++j)
+            for (int j = 0; j < C::XV; ++j) {
                 *reinterpret_cast<f32x4*>(dst + C::ROWS_PER_PASS * ROW * j) = sw.xv[j];
+                if constexpr (SELF && AM >= 0) xacc[j][AM] = sq4(sw.xv[j], xacc[j][AM]);
+            }
 #pragma unroll
             for (int j = 0; j < C::WV; ++j)
                 *reinterpret_cast<f32x4*>(dst + C::X_IMG + C::ROWS_PER_PASS * ROW * j) = sw.wv[j];
@@ -723,16 +770,61 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
-        if (D2) {
+        if (SELF && ct == 0) {
+            // first code tile.  The body of MFMA chunk c writes chunk c + 1 of the X tile to LDS (loaded one body
+            // earlier): those rows feed accumulator (c + 1) % 8; the tile's last body writes chunk 0 of the NEXT
+            // pass over X and feeds nothing.  The loop keeps its two-bodies-per-trip shape (unrolling it by 8 to get
+            // literal accumulator indices spilled 153 registers): the accumulators are a ring that is turned by two
+            // places after every trip, so the bodies always feed places 1 and 2; n_chunks % 8 == 0 brings the ring
+            // back to its starting position at the end of the tile.
+            using A1 = std::integral_constant<int, 1>;
+            using A2 = std::integral_constant<int, 2>;
+            auto turn = [&]() {
+#pragma unroll
+                for (int j = 0; j < C::XV; ++j) {
+                    const float t0 = xacc[j][0], t1 = xacc[j][1];
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) xacc[j][m] = xacc[j][m + 2];
+                    xacc[j][6] = t0;
+                    xacc[j][7] = t1;
+                }
+            };
             for (int kc = 0; kc + 2 < n_chunks; kc += 2) {
-                body(wpc, (kc + 2) * BKC, P0());
-                body(wpc, (kc + 3) * BKC, P1());
+                body(wpc, (kc + 2) * BKC, P0(), A1());
+                body(wpc, (kc + 3) * BKC, P1(), A2());
+                turn();
             }
-            body(wpn, 0, P0());     // last two chunks: stage chunks 0 and 1 of the next tile
-            body(wpn, BKC, P1());   // (harmless reloads on the last tile)
+            body(wpn, 0, P0(), A1());
+            body(wpn, BKC, P1(), NoAcc());
+            turn();
+            if (!xx) {
+                // the xor butterfly of wave_sum: lane bits 5..3 = the 8 accumulators of a thread, bits 2..0 = the 8
+                // threads of a row (tid % 8); the row's sum goes through LDS to the lane that holds the token
+                float* xs_ = lds + 2 * C::STAGE;   // 128 floats behind the two stages
+#pragma unroll
+                for (int j = 0; j < C::XV; ++j) {
+                    const float n0 = xacc[j][0] + xacc[j][4], n1 = xacc[j][1] + xacc[j][5];
+                    const float n2 = xacc[j][2] + xacc[j][6], n3 = xacc[j][3] + xacc[j][7];
+                    const float p0 = n0 + n2, p1 = n1 + n3;
+                    float q = p0 + p1;
+                    q += __shfl_xor(q, 4);
+                    q += __shfl_xor(q, 2);
+                    q += __shfl_xor(q, 1);
+                    if ((tid & 7) == 0) xs_[s_row + C::ROWS_PER_PASS * j] = q;
+                }
+                __syncthreads();
+                xv = xs_[wave * 32 + l31];
+            }
+        } else if (D2) {
+            for (int kc = 0; kc + 2 < n_chunks; kc += 2) {
+                body(wpc, (kc + 2) * BKC, P0(), NoAcc());
+                body(wpc, (kc + 3) * BKC, P1(), NoAcc());
+            }
+            body(wpn, 0, P0(), NoAcc());     // last two chunks: stage chunks 0 and 1 of the next tile
+            body(wpn, BKC, P1(), NoAcc());   // (harmless reloads on the last tile)
         } else {
-            for (int kc = 1; kc < n_chunks; ++kc) body(wpc, kc * BKC, P0());
-            body(wpn, 0, P0());   // last chunk of the tile: stage chunk 0 of the next tile
+            for (int kc = 1; kc < n_chunks; ++kc) body(wpc, kc * BKC, P0(), NoAcc());
+            body(wpn, 0, P0(), NoAcc());   // last chunk of the tile: stage chunk 0 of the next tile
         }
 #pragma unroll
         for (int j = 0; j < C::WV; ++j) wpc[j] = wpn[j];
@@ -782,7 +874,9 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
             if (RANGED) gi -= r_start;
             key = pack_key(best, static_cast<int>(gi));
         }
-        if (atomic_merge) {
+        if (SELF) {
+            keys[static_cast<size_t>(split) * N + tok] = key;   // one slot per (split, token): no prefill, no atomics
+        } else if (atomic_merge) {
             if (key != KEY_NONE) atomicMin(keys + tok, key);
         } else {
             keys[tok] = key;
@@ -969,12 +1063,14 @@ __device__ __forceinline__ void build_groups(const int* s_code, unsigned long lo
     if (lane == 0) *s_ngroups = __popcll(lead_mask);
 }
 
+// key_sets > 1: the token's key is the minimum of keys[s * N + token], s < key_sets (the per-split slots the
+// self-contained distance kernel writes).
 template <int NCH, bool COSINE, int TOK>
 __global__ __launch_bounds__(256) void gather_stats_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const long long* __restrict__ keys, int N, int K,
     int D, float* __restrict__ out_ste, float* __restrict__ out_q, float* __restrict__ out_diff,
     long long* __restrict__ idx_out, int stats_begin, int stats_count, float* __restrict__ counts,
-    float* __restrict__ embed_sum, float* __restrict__ loss_partial, const int* __restrict__ perm) {
+    float* __restrict__ embed_sum, float* __restrict__ loss_partial, const int* __restrict__ perm, int key_sets) {
     extern __shared__ __attribute__((aligned(16))) float tbuf[];  // [4 waves][NCH*256] transposition rows
     __shared__ int s_code[TOK];
     __shared__ int s_tok[TOK];   // the workgroup's tokens: positions tok0.. of `perm` (tokens ordered by code), or tok0.. itself
@@ -993,7 +1089,12 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
         int code = -1, real = 0;
         if (tid < n_here) {
             real = perm ? perm[tok0 + tid] : tok0 + tid;
-            code = key_index(keys[real]);
+            long long key = keys[real];
+            for (int ks = 1; ks < key_sets; ++ks) {
+                const long long o = keys[static_cast<size_t>(ks) * N + real];
+                key = o < key ? o : key;
+            }
+            code = key_index(key);
             code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
             if (idx_out) idx_out[real] = code;
         }
@@ -1891,6 +1992,52 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
 #undef T5VQ_GO2
 }
 
+// ---- the self-contained form of the search for small problems (dist_mfma_v2_kernel<CfgSmall, .., SELF>) ------------
+// Applies when the problem has fewer than 256 tiles of 128 x 128 (the rule that selects the 128 x 64 tile), the search
+// is plain (no ranges), D % 256 == 0 and the tuning knobs are at their defaults.  With it a composite forward is
+// [distance + argmin] -> [gather + statistics] with nothing in front: C2 (N = 4096, K = 512) saves the row-norm /
+// preparation launch, its 4 us and the gap behind it.
+constexpr int64_t SELF_MAX_KEY_SLOTS = 65536;   // splits x N never exceeds this for a problem the rule admits
+
+bool self_shape(int64_t N, int64_t K) {
+    return ((N + TOK_TILE - 1) / TOK_TILE) * ((K + 127) / 128) < 256;
+}
+bool self_applicable(int64_t N, int64_t K, int64_t D, const int64_t* range) {
+    return !range && D % 256 == 0 && self_shape(N, K) && g_dist_variant == 0 && g_force_splits == 0 && g_depth2;
+}
+
+int launch_dist_self(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K, int64_t D,
+                     int64_t* key_slots, SelfArgs self, int* splits_out, hipStream_t stream) {
+    using C = CfgSmall;
+    constexpr int LDS = C::LDS_BYTES + TOK_TILE * 4;   // + the row norms of the token tile
+    T5VQ_REQUIRE(x && w && ee && key_slots, "null input");
+    T5VQ_REQUIRE(aligned16(x) && aligned16(w) && aligned16(ee), "x, w, ee must be 16-byte aligned");
+    for (int r = 0; r < 2; ++r)
+        T5VQ_REQUIRE(self.nz[r] % 4 == 0 && (self.nz[r] == 0 || (self.zero[r] && aligned16(self.zero[r]))),
+                     "statistics buffers must be 16-byte aligned and a multiple of 4 floats long");
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    T5VQ_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
+        T5VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_mfma_v2_kernel<C, false, true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
+    const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
+    const int64_t splits = plan_splits(N, K, D, C::CODE_TILE, nullptr);
+    T5VQ_REQUIRE(splits * N <= SELF_MAX_KEY_SLOTS, "internal: more key slots than the workspace holds");
+    const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
+    const dim3 grid(static_cast<unsigned>((tok_tiles + 7) / 8 * 8 * splits));
+    hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, true, true>), grid, dim3(256), LDS, stream, x, w, xx, ee,
+                       static_cast<const long long*>(nullptr), static_cast<int>(N), static_cast<int>(K),
+                       static_cast<int>(D), static_cast<int>(splits), static_cast<int>(tiles_per_split), 0LL, 0,
+                       reinterpret_cast<long long*>(key_slots), self);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    *splits_out = static_cast<int>(splits);
+    return T5VQ_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -1967,7 +2114,8 @@ int t5vq_unpack_keys(const int64_t* keys, int64_t N, int64_t* idx, float* dmin, 
 static int launch_gather(const float* x, const float* w, const int64_t* keys, int64_t N, int64_t K, int64_t D,
                          int loss_kind, float* out_ste, float* out_q, float* out_diff, int64_t* idx_out,
                          int64_t stats_begin, int64_t stats_count, float* counts, float* embed_sum,
-                         float* loss_partial, bool stats_zeroed, const int32_t* perm, hipStream_t stream) {
+                         float* loss_partial, bool stats_zeroed, const int32_t* perm, hipStream_t stream,
+                         int key_sets = 1) {
     T5VQ_REQUIRE(x && w && keys, "null input");
     T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31), "N, K out of range");
     T5VQ_REQUIRE(D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
@@ -1993,7 +2141,7 @@ static int launch_gather(const float* x, const float* w, const int64_t* keys, in
     hipLaunchKernelGGL((gather_stats_kernel<NCH_, COS_, TOK_>), grid, dim3(256), lds, stream, x, w, kp,             \
                        static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), out_ste, out_q, out_diff, ip, \
                        static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial, \
-                       perm)
+                       perm, key_sets)
 #define T5VQ_GS(NCH_, COS_)                                   \
     if (gs_tok(N) == GS_TOK_SMALL) {                          \
         T5VQ_GS_T(NCH_, COS_, GS_TOK_SMALL);                  \
@@ -2332,8 +2480,8 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 struct FwdWorkspace {
     int64_t keys, xx, ee, partial, perm, work, total;
     FwdWorkspace(int64_t N, int64_t K) {
-        keys = 0;                                                   // int64 [N]
-        xx = align_up(8 * N, 16);                                   // fp32 [N]
+        keys = 0;                                                   // int64 [N]; small problems: [splits][N] key slots
+        xx = align_up(8 * (self_shape(N, K) ? SELF_MAX_KEY_SLOTS : N), 16);   // fp32 [N]
         ee = align_up(xx + 4 * N, 16);                              // fp32 [padded(K)], 16-byte aligned
         partial = align_up(ee + 4 * t5vq_padded_codes(K), 16);      // fp32 [gather_blocks(N)], [N] with ordered tokens
         perm = align_up(partial + 4 * N, 16);                       // int32 [N]: tokens ordered by code
@@ -2368,6 +2516,27 @@ static int vq_forward_impl(const float* x, const float* w, const int64_t* range,
     const float* ee = ee_in ? ee_in : reinterpret_cast<float*>(base + ws.ee);
     float* partial = loss_terms ? loss_terms : (loss_sum ? reinterpret_cast<float*>(base + ws.partial) : nullptr);
     const bool order = embed_sum && N >= GS_SMALL_N;   // statistics wanted, enough tokens for the ordering to pay
+    if (self_applicable(N, K, D, range) && !order && K % 4 == 0 && (K * D) % 4 == 0 &&
+        (!counts || aligned16(counts)) && (!embed_sum || aligned16(embed_sum))) {
+        // small problem: [|e|^2 only if it was not given] -> [self-contained distance + argmin] -> [gather + statistics]
+        int rc = T5VQ_OK;
+        if (!ee_in) {
+            rc = launch_row_sqnorms(nullptr, 0, nullptr, w, K, reinterpret_cast<float*>(base + ws.ee), D, PrepArgs{}, stream);
+            if (rc != T5VQ_OK) return rc;
+        }
+        SelfArgs sa{};
+        sa.zero[0] = counts;
+        sa.nz[0] = counts ? K : 0;
+        sa.zero[1] = embed_sum;
+        sa.nz[1] = embed_sum ? K * D : 0;
+        int splits = 1;
+        rc = launch_dist_self(x, w, xx_in, ee, N, K, D, keys, sa, &splits, stream);
+        if (rc != T5VQ_OK) return rc;
+        rc = launch_gather(x, w, keys, N, K, D, loss_kind, out_ste, out_q, out_diff, idx_out, 0, K, counts, embed_sum,
+                           partial, true, nullptr, stream, splits);
+        if (rc != T5VQ_OK || !loss_sum) return rc;
+        return t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
+    }
     PrepArgs prep{};
     prep.zero_a = counts;
     prep.n_a = counts ? K : 0;

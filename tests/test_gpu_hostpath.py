@@ -186,3 +186,55 @@ def test_given_row_norms_are_consumed_by_both_searches(search):
     assert torch.equal(got[3], want[3]) and torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
     keys_s = ops.dist_argmin(flat, m._embedding.weight.detach(), xx_p, ops.code_sqnorms(m._embedding.weight.detach()))
     assert torch.equal(ops.unpack_keys(keys_s)[0], got[3].view(-1))
+
+
+@pytest.mark.parametrize("n,k,d,given", [(4096, 512, 768, "none"), (4096, 512, 768, "ee"), (4096, 512, 768, "both"),
+                                         (1000, 640, 256, "none"), (130, 128, 512, "ee"), (129, 2048, 1024, "xx"),
+                                         (3000, 1000, 768, "none"), (64, 4, 256, "none")])
+def test_self_contained_small_search_equals_the_chain(n, k, d, given):
+    """Small problems (fewer than 256 tiles of 128 x 128, D % 256 == 0, plain search) take the self-contained distance
+    kernel inside the composite forward: |x|^2 from the staged X tile, per-split key slots merged by the gather
+    kernel, statistics zeroed on the way -- no launch in front of it.  Everything it produces must equal the chain of
+    fine-grained entry points (row norms -> distance + argmin with atomicMin merge -> gather) bit for bit."""
+    w = synth.normal((k, d), 21, 0, device=DEV)
+    x, _ = synth.clustered(n, w, 0.7, 22)
+    xx, ee = ops.row_sqnorms(x, w)
+
+    def bufs():
+        return dict(ste=torch.full_like(x, float("nan")), diff=torch.full_like(x, float("nan")),
+                    idx=torch.full((n,), -1, dtype=torch.int64, device=DEV),
+                    counts=torch.full((k,), float("nan"), device=DEV),
+                    embed_sum=torch.full((k, d), float("nan"), device=DEV))
+    a, b = bufs(), bufs()
+    ls_a, ls_b = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    ops.vq_forward(x, w, None, "mse", xx=xx if given in ("xx", "both") else None,
+                   ee=ee if given in ("ee", "both") else None, loss_sum=ls_a, **a)
+    keys = ops.dist_argmin(x, w, xx, ee)
+    part = torch.empty(ops.gather_blocks(n), device=DEV)
+    ops.gather_stats(x, w, keys, "mse", loss_partial=part, **b)
+    ops.reduce_partials(part, ls_b)
+    for name in ("idx", "ste", "diff", "counts"):
+        assert torch.equal(a[name], b[name]), name
+    assert torch.equal(ls_a, ls_b)
+    assert rel(a["embed_sum"], b["embed_sum"]) <= 1e-6
+    # and twice in a row on the same buffers (nothing is carried over in the key slots)
+    ops.vq_forward(x, w, None, "mse", loss_sum=ls_a, **a)
+    assert torch.equal(a["idx"], b["idx"]) and torch.equal(ls_a, ls_b)
+
+
+def test_self_contained_search_ties_and_eval_module():
+    """Exact duplicates across code splits resolve to the lowest index when the splits' key slots are merged; the
+    module's evaluation path at C2's shape goes through the same kernel and agrees with get_indices (fine-grained)."""
+    k, d, n = 512, 768, 4096
+    m = _fresh(k, d, 23)
+    with torch.no_grad():
+        for dup in (70, 200, 511):                       # other 64-code tiles = other splits
+            m._embedding.weight[dup] = m._embedding.weight[5]
+    x = synth.normal((1, n, d), 24, 0).to(DEV)
+    with torch.no_grad():
+        x.view(-1, d)[:8] = m._embedding.weight[5]
+    m.eval()
+    m.search = "scan"
+    out = m(x)
+    assert (out[3].view(-1)[:8] == 5).all()
+    assert torch.equal(out[3], m.get_indices(x))
