@@ -149,6 +149,23 @@ def roofline_fracs(n, k, d, update, ms):
             "algorithmic_flops": flops, "algorithmic_bytes": step_bytes(n, k, d, update)}
 
 
+def back_to_back_ms(mod, x, w, ema_w, cs, iters):
+    """The same call queued back to back (no host wait between calls, state reset once before): what a training loop
+    that never synchronises sees.  HIP events around the whole run."""
+    import torch
+    with torch.no_grad():
+        mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
+        for _ in range(3):
+            mod(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            mod(x)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def per_call_ms(mod, x, w, ema_w, cs, iters):
     """One call per measurement: state reset OUTSIDE the timed region, HIP events around the call on the stream the
     kernels run on (torch's current stream is the one the extension launches on).  (median, min) in ms."""
@@ -300,6 +317,10 @@ def single_gpu_configs(args, dev):
                  "search": args.search, "ms_per_call_median": med, "ms_per_call_min": mn,
                  "vectors_per_s": n / (med * 1e-3), "codes_used": int(res[3].unique().numel())}
         entry.update(roofline_fracs(n, k, d, update, med))
+        if regime == "uniform":           # queued back to back the state is not reset: only the stationary regime
+            b2b = back_to_back_ms(mod, x, w, ema_w, cs, 2 * args.config_iters)
+            entry["ms_back_to_back"] = b2b
+            entry["frac_of_mfma_roofline_back_to_back"] = (2.0 * n * k * d / PEAK_FP32_MFMA_TFLOPS / 1e12) / (b2b * 1e-3)
         if not args.no_cpu_baseline:
             leg = cpu_leg(k, d, update, args.search, state, dev, 2880 if wl == "c1" else 4096, 0.0, desc)
             entry["parity"] = leg["parity"]

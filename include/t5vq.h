@@ -282,7 +282,8 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
  * same results; the per-call temporaries (keys, |x|^2, |e|^2, loss terms, token order, sort cursors) live in a
  * library-owned static device array of T5VQ_NOALLOC_SCRATCH_BYTES (one copy per GPU the library runs on, held until
  * the process ends; its device address is looked up once per device on the first call there, with that device
- * current).  The call allocates and frees nothing.  Limit: t5vq_forward_workspace_bytes(N, K) (about 20 N + 8 K bytes)
+ * current).  The call allocates and frees nothing.  Limit: t5vq_forward_workspace_bytes(N, K) (about 20 N + 8 K bytes,
+ * plus 512 KB of key slots for problems of fewer than 256 tiles of 128 x 128)
  * must not exceed T5VQ_NOALLOC_SCRATCH_BYTES -- e.g. N = 131072 with K = 16384, or N = 65536 with K = 65536;
  * larger shapes return T5VQ_ERR_INVALID with a message.  Every call on a GPU shares that GPU's array: calls that
  * overlap on one GPU (two streams, two host threads) race on it -- serialise them; calls on one stream are ordered
