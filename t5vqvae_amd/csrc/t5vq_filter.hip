@@ -31,7 +31,11 @@ constexpr long long KEY_NONE = 0x7FFFFFFFFFFFFFFFLL;
 constexpr int CAND_MAX = 16;            // candidates kept per token; more -> exact scan of all codes for that token
 constexpr int KEEP = 4;                 // lowest lower bounds each scanner keeps (a scanner = one lane half of one
                                         // wave of one code split: it sees a fixed subset of the codes of its token)
+#ifdef T5VQ_FILTER_W4   // experiment: 4 waves of 128 tokens x 128 codes (16 accumulators each) instead of 8 of 64 x 128
+constexpr int TOK_TILE = 256, CODE_TILE = 256, THREADS = 256;
+#else
 constexpr int TOK_TILE = 256, CODE_TILE = 256, THREADS = 512;
+#endif
 constexpr int BKC = 32;                 // 16-byte-aligned chunk of a row, in 4-byte units = 64 fp16
 constexpr int ROW = BKC;                // unpadded 128-byte rows (an LDS-DMA instruction writes 1 KB contiguously); the
                                         // 16-byte slot of piece p in row r is p ^ ((r >> 1) & 7): conflict-free b128 reads
@@ -42,7 +46,12 @@ constexpr int EPI = 3 * CODE_TILE;         // per code of the tile: |e|^2, |e|, 
 constexpr int LDS_BYTES = (2 * STAGE + 2 * EPI) * 4;   // 131,072 + 6,144 B: one workgroup (8 waves) per CU
 constexpr int F4_PER_ROW = BKC / 4, ROWS_PER_PASS = THREADS / F4_PER_ROW, XV = TOK_TILE / ROWS_PER_PASS,
               WV = CODE_TILE / ROWS_PER_PASS, G = BKC / 8;
+#ifdef T5VQ_FILTER_W4
+constexpr int TB = 4, CB = 4;           // 32x32 blocks per wave: 128 tokens x 128 codes
+#else
 constexpr int TB = 2, CB = 4;           // 32x32 blocks per wave: 64 tokens x 128 codes
+#endif
+constexpr int WAVES_T = TOK_TILE / (32 * TB);   // waves side by side along the tokens (the rest along the codes)
 
 __device__ __forceinline__ int order_image(float d) {
     const int b = __float_as_int(d);
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     float* __restrict__ lbuf, int* __restrict__ cbuf, int* __restrict__ tshare) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wt = wave & 3, wc = wave >> 2;
+    const int wt = wave % WAVES_T, wc = wave / WAVES_T;
     // Large problems: the splits of one token tile get ids 8 apart (one XCD, shared X tile in its L2).  Small problems
     // (plain_map: at most a few workgroups per CU in total): consecutive ids are different token tiles, so the
     // workgroups spread evenly over the XCDs -- with 12 token tiles the XCD-affine map loads 4 XCDs twice as much.
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
         scan_init(sc[b]);
-        tok[b] = tok_base + wt * 64 + b * 32 + l31;
+        tok[b] = tok_base + wt * (32 * TB) + b * 32 + l31;
         const int tc = tok[b] < N ? tok[b] : N - 1;
         xv[b] = xx[tc];
         csx[b] = c2 * sqrtf(xv[b]);
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
             // chunk of the tile, written during the second, read after the tile's last barrier -- read from global
             // memory in the epilogue itself, every group of four codes waited a full L2 latency
             float* epi = lds + 2 * STAGE + (ct & 1) * EPI;
-            float ep0 = 0.f, ep1 = 0.f;
+            float ep0 = 0.f, ep1 = 0.f, ep2 = 1.f;
             int shared_u[TB];
             for (int kc = 0; kc < n_chunks; ++kc, ++it) {
                 if (kc == 0) {
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                     if (tid < CODE_TILE) {
                         ep0 = c < kpad ? ee[c] : __int_as_float(0x7F800000);
                         ep1 = c < kpad ? se[c] : 0.f;
+                        if (THREADS < 2 * CODE_TILE) ep2 = c < kpad ? w_inv[c] : 1.f;
                     } else {
                         ep0 = c < kpad ? w_inv[c] : 1.f;
                     }
@@ -356,11 +366,12 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
                     if (tid < CODE_TILE) {
                         epi[tid] = ep0;
                         epi[CODE_TILE + tid] = ep1;
+                        if (THREADS < 2 * CODE_TILE) epi[2 * CODE_TILE + tid] = ep2;
                     } else {
                         epi[2 * CODE_TILE + (tid & (CODE_TILE - 1))] = ep0;
                     }
                 }
-                const float* xs = lds + (it & 1) * STAGE + (wt * 64 + l31) * ROW;
+                const float* xs = lds + (it & 1) * STAGE + (wt * (32 * TB) + l31) * ROW;
                 const float* ws = lds + (it & 1) * STAGE + X_IMG + (wc * 128 + l31) * ROW;
                 // stage it+1 goes straight into the other buffer (free since the barrier that ended step it-1) and
                 // must have landed by this step's closing barrier; past the end the last stage is fetched again
