@@ -82,7 +82,8 @@ int main(int argc, char** argv) {
     float* loss_sum = counts + K;
 
     // the filtered search first (it reads the pre-update codebook, like the forward below)
-    VQ_OK(t5vq_dist_argmin_filtered_f32(x, w, xx, ee, /*compute_norms=*/1, /*range=*/nullptr, N, K, D, /*code_offset=*/0,
+    VQ_OK(t5vq_dist_argmin_filtered_f32(x, w, xx, ee, /*compute_norms=*/1, /*range=*/nullptr, /*order=*/nullptr, N, K, D,
+                                        /*code_offset=*/0,
                                         /*exact_keys=*/1, ws_f, wsf_bytes, keys_f, unsettled, stream));
     // forward: indices, straight-through output, loss terms, EMA statistics (vqvae/vqvae.py:103-160)
     VQ_OK(t5vq_vq_forward_f32(x, w, nullptr, /*xx_in=*/nullptr, /*ee_in=*/nullptr, N, K, D, T5VQ_LOSS_MSE, ws, ws_bytes,

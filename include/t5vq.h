@@ -42,12 +42,13 @@ typedef void* t5vq_stream_t; /* hipStream_t */
 int t5vq_version(void);
 const char* t5vq_last_error(void);
 /* Diagnostic: select a tile configuration of the distance kernel (0 = shipped default; other values only
- * exist in builds made with -DT5VQ_TUNING and otherwise fall back to the default).  No reference counterpart. */
+ * exist in builds made with -DT5VQ_TUNING and otherwise fall back to the default).  The setting belongs to the
+ * calling thread: launches made from other threads keep the default.  No reference counterpart. */
 int t5vq_set_tuning(int variant);
 /* Length of the padded |e|^2 buffer for K codes: K rounded up to T5VQ_CODE_PAD. */
 int64_t t5vq_padded_codes(int64_t K);
 /* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens (a workgroup takes 64 tokens,
- * or 16 when N < 32768 so that small batches still cover the CUs). */
+ * 16 when N < 32768 and 4 when N < 8192, so that small batches still cover the CUs). */
 int64_t t5vq_gather_blocks(int64_t N);
 
 /* Row squared norms of two matrices in one launch.
@@ -70,10 +71,23 @@ int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, i
  * code_offset is the global id of w's first row (0 unless the codebook is sharded by code).
  * merge == 0: keys are overwritten.  merge != 0: keys already hold valid packed keys (e.g. from another
  * codebook shard) and are min-merged.  Rows whose range misses this shard keep INT64_MAX / their old key.
- * ee must be the padded buffer written by t5vq_row_sqnorms_f32. */
+ * ee must be the padded buffer written by t5vq_row_sqnorms_f32.
+ * order (nullable; only with range): a permutation of the token ids, the sequence in which the kernel's 128-token
+ * tiles take the tokens (t5vq_order_by_range puts tokens of one role next to each other, so a tile carries one or two
+ * ranges and skips every code tile outside them: 2 D sum_r N_r K_r flops instead of 2 D N K).  Speed only: x, xx,
+ * range and keys stay indexed by token, nothing is moved, the keys are the same with and without it. */
 int t5vq_dist_argmin_f32(const float* x, const float* w, const float* xx, const float* ee,
-                         const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
-                         int merge, int64_t* keys, t5vq_stream_t stream);
+                         const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                         int64_t code_offset, int merge, int64_t* keys, t5vq_stream_t stream);
+
+/* order[0..N) = the token ids grouped by their code range (disentangled mode: the (start, end) pairs of
+ * batch['srl'], t5/load_data.py:68-99, as the loop at vqvae/vqvae.py:110-119 reads them): a counting sort over
+ * (start, end) buckets of 128 codes or more; the order inside a bucket is not specified.  K, code_offset: the
+ * codebook (slice) the ranges will be searched in.  work: K + 8 int32 of scratch.  The composite forwards do this
+ * themselves (from 1024 tokens on); the call is for users of the fine-grained searches.  No reference counterpart
+ * (the reference visits token after token). */
+int t5vq_order_by_range(const int64_t* range, int64_t N, int64_t K, int64_t code_offset, int32_t* order,
+                        int32_t* work, t5vq_stream_t stream);
 
 /* Unpack keys -> indices (int64, what torch.argmin returns, vqvae/vqvae.py:122) and/or distances.
  * Either output may be NULL. */
@@ -207,11 +221,13 @@ int t5vq_one_hot_f32(const int64_t* idx, int64_t N, int64_t K, float* enc, t5vq_
  * to t5vq_row_sqnorms_f32), which saves that launch and its read of x.
  * compute_norms == 2: xx is an input, ee an output.  compute_norms == 3: xx is an output, ee an input.
  * workspace: t5vq_filter_workspace_bytes(N, K, D) bytes, 256-byte aligned (fp16 images of x and w, bounds,
- * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan. */
+ * candidate lists).  n_overflow (nullable, device int32): number of tokens that took the fp32 scan.
+ * order (nullable; only with range): as for t5vq_dist_argmin_f32 -- the fp16 image of x is laid out in that order,
+ * x itself is not moved; xx and keys stay indexed by token. */
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D);
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
-                                  const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
-                                  int exact_keys, void* workspace, int64_t workspace_bytes,
+                                  const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                                  int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream);
 
 /* ---- Evaluation-side searches (callers of the path in evaluate_vqvae.py) ----------------

@@ -26,7 +26,8 @@ SIGNATURES = {
     "t5vq_padded_codes": (I64, [I64]),
     "t5vq_gather_blocks": (I64, [I64]),
     "t5vq_row_sqnorms_f32": (c_int, [P, I64, P, P, I64, P, I64, P]),
-    "t5vq_dist_argmin_f32": (c_int, [P, P, P, P, P, I64, I64, I64, I64, c_int, P, P]),
+    "t5vq_dist_argmin_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P, P]),
+    "t5vq_order_by_range": (c_int, [P, I64, I64, I64, P, P, P]),
     "t5vq_unpack_keys": (c_int, [P, I64, P, P, P]),
     "t5vq_distances_f32": (c_int, [P, P, P, P, I64, I64, I64, P, P]),
     "t5vq_gather_stats_f32": (c_int, [P, P, P, I64, I64, I64, c_int, P, P, P, P, I64, I64, P, P, P, P, P]),
@@ -43,7 +44,7 @@ SIGNATURES = {
     "t5vq_cosine_backward_f32": (c_int, [P, P, P, P, c_float, c_float, I64, I64, P, P, P]),
     "t5vq_one_hot_f32": (c_int, [P, I64, I64, P, P]),
     "t5vq_filter_workspace_bytes": (I64, [I64, I64, I64]),
-    "t5vq_dist_argmin_filtered_f32": (c_int, [P, P, P, P, c_int, P, I64, I64, I64, I64, c_int, P, I64, P, P, P]),
+    "t5vq_dist_argmin_filtered_f32": (c_int, [P, P, P, P, c_int, P, P, I64, I64, I64, I64, c_int, P, I64, P, P, P]),
     "t5vq_dist_topk_f32": (c_int, [P, P, P, P, I64, I64, I64, I64, P, P]),
     "t5vq_blend_argmin_f32": (c_int, [P, P, c_float, c_float, I64, I64, P, P]),
     "t5vq_rmsnorm_sqnorms_f32": (c_int, [P, P, P, c_float, c_float, I64, I64, P, P, P, P]),

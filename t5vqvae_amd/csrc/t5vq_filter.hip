@@ -66,6 +66,9 @@ __device__ __forceinline__ long long pack_key(float d, int idx) {
 // down to 2^-28 of the row maximum keep 11 significant bits.  inv[row] = the inverse factor (a power of two).
 // One wave per row; se[k] = sqrt(ee[k]) for the error bound.
 // norm_x / norm_w: this pass also writes |x|^2 / |e|^2 (otherwise they are inputs).
+// order (nullable, ranged search): image row p is made from token order[p] -- the filter kernel then walks the tokens
+// role by role although x itself is never moved; everything indexed by image row (xh, x_inv, tshare, the scanner
+// records) is internal, everything the caller sees (xx, keys) stays indexed by token.
 template <int NCH>
 __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restrict__ x, long long n_x,
                                                           _Float16* __restrict__ xh, float* __restrict__ x_inv,
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           long long kpad, float* __restrict__ se, int D,
                                                           int* __restrict__ n_list, int* __restrict__ tshare,
                                                           unsigned row_blocks, T5vqZeroArgs zero, int norm_x,
-                                                          int norm_w) {
+                                                          int norm_w, const int* __restrict__ order) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= row_blocks) {   // the tail of the grid zeroes the caller's buffers: 4096 words per workgroup
         long long i = (static_cast<long long>(blockIdx.x - row_blocks) * 256 + threadIdx.x) * 16;
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
     float* norm;      // NORMS: where this row's squared norm goes (xx or ee)
     const bool is_w = row >= n_x;
     if (!is_w) {
-        src = x + row * D; dst = xh + row * D; inv = x_inv + row; norm = xx + row;
+        const long long token = order ? order[row] : row;
+        src = x + token * D; dst = xh + row * D; inv = x_inv + row; norm = xx + token;
         if (lane == 0) tshare[row] = 0x7F800000;   // order image of +inf: no bound yet
     } else {
         row -= n_x;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     const float* __restrict__ ee, const float* __restrict__ se, const float* __restrict__ x_inv,
     const float* __restrict__ w_inv, int N, int K, int kpad, int D2, int n_splits, int tiles_per_split, int plain_map,
     float c2, float r, const long long* __restrict__ range, long long code_offset, float* __restrict__ ubuf,
-    float* __restrict__ lbuf, int* __restrict__ cbuf, int* __restrict__ tshare) {
+    float* __restrict__ lbuf, int* __restrict__ cbuf, int* __restrict__ tshare, const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int wt = wave % WAVES_T, wc = wave / WAVES_T;
@@ -247,15 +251,16 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     for (int b = 0; b < TB; ++b) {
         scan_init(sc[b]);
         tok[b] = tok_base + wt * (32 * TB) + b * 32 + l31;
-        const int tc = tok[b] < N ? tok[b] : N - 1;
-        xv[b] = xx[tc];
+        const int tc = tok[b] < N ? tok[b] : N - 1;                    // image row
+        const int real = (RANGED && order) ? order[tc] : tc;           // the token it was made from
+        xv[b] = xx[real];
         csx[b] = c2 * sqrtf(xv[b]);
         m2[b] = -2.0f * x_inv[tc];   // -2 and the token row's inverse scale: exact (power of two)
         ls[b] = 0;
         le[b] = K;
         if (RANGED) {
-            long long a = range[2 * static_cast<size_t>(tc)] - code_offset;
-            long long e = range[2 * static_cast<size_t>(tc) + 1] - code_offset;
+            long long a = range[2 * static_cast<size_t>(real)] - code_offset;
+            long long e = range[2 * static_cast<size_t>(real) + 1] - code_offset;
             a = a < 0 ? 0 : (a > K ? K : a);
             e = e < 0 ? 0 : (e > K ? K : e);
             ls[b] = static_cast<int>(a);
@@ -538,16 +543,18 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
                                                       int exact_keys, const long long* __restrict__ range,
                                                       long long code_offset, int* __restrict__ pair_tok,
                                                       int* __restrict__ pair_code, long long* __restrict__ keys,
-                                                      int* __restrict__ tok_list, int* __restrict__ n_list) {
+                                                      int* __restrict__ tok_list, int* __restrict__ n_list,
+                                                      const int* __restrict__ order) {
     const long long gid = static_cast<long long>(blockIdx.x) * COLLECT_THREADS + threadIdx.x;
-    const int tok = static_cast<int>(gid / L), s = static_cast<int>(gid % L);
+    const int tok = static_cast<int>(gid / L), s = static_cast<int>(gid % L);   // tok: image row (scanner records)
     // No lane leaves early: the pair counter below is reserved once per WORKGROUP (prefix sums over all its lanes).
     bool active = tok < N;
+    const int real = (active && order) ? order[tok] : tok;   // the token: ranges, keys and the two lists are by token
     if (active && range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
-        const long long a = range[2 * static_cast<size_t>(tok)] - code_offset;
-        const long long e = range[2 * static_cast<size_t>(tok) + 1] - code_offset;
+        const long long a = range[2 * static_cast<size_t>(real)] - code_offset;
+        const long long e = range[2 * static_cast<size_t>(real) + 1] - code_offset;
         if ((e < K ? e : K) <= (a > 0 ? a : 0)) {
-            if (s == 0) keys[tok] = KEY_NONE;
+            if (s == 0) keys[real] = KEY_NONE;
             active = false;
         }
     }
@@ -606,21 +613,21 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
     if (!active) return;
     if (to_scan) {
         if (s == 0) {
-            keys[tok] = KEY_NONE;               // the listed scan merges into it with atomicMin
-            tok_list[list_slot] = tok;
+            keys[real] = KEY_NONE;              // the listed scan merges into it with atomicMin
+            tok_list[list_slot] = real;
         }
     } else if (decided) {                       // the index is decided; T_i (an upper bound of its distance) fills
         if (s == 0) {
-            const long long gi = code_offset + f - (range ? range[2 * static_cast<size_t>(tok)] : 0);
-            keys[tok] = pack_key(T, static_cast<int>(gi));   // the key's distance word (index: slice-relative if ranged)
+            const long long gi = code_offset + f - (range ? range[2 * static_cast<size_t>(real)] : 0);
+            keys[real] = pack_key(T, static_cast<int>(gi));  // the key's distance word (index: slice-relative if ranged)
         }
     } else {   // refine_kernel merges the pairs' exact keys into the token's key with atomicMin
-        if (s == 0) keys[tok] = KEY_NONE;
+        if (s == 0) keys[real] = KEY_NONE;
         int slot = tok_base + incl - q;
 #pragma unroll
         for (int i = 0; i < R * KEEP; ++i)
             if (ok[i]) {
-                pair_tok[slot] = tok;
+                pair_tok[slot] = real;
                 pair_code[slot] = c[i];
                 ++slot;
             }
@@ -734,20 +741,21 @@ int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
 }
 
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
-                                  const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
-                                  int exact_keys, void* workspace, int64_t workspace_bytes,
+                                  const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                                  int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     T5vqZeroArgs zero = {};
-    return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, N, K, D, code_offset, exact_keys,
+    return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, order, N, K, D, code_offset, exact_keys,
                                               workspace, workspace_bytes, keys, n_overflow, zero,
                                               static_cast<hipStream_t>(stream_));
 }
 
 int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
-                                       const int64_t* range, int64_t N, int64_t K, int64_t D, int64_t code_offset,
-                                       int exact_keys, void* workspace, int64_t workspace_bytes, int64_t* keys,
-                                       int32_t* n_overflow, T5vqZeroArgs zero, hipStream_t stream) {
+                                       const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                                       int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
+                                       int64_t* keys, int32_t* n_overflow, T5vqZeroArgs zero, hipStream_t stream) {
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
+    T5VQ_I_REQUIRE(!order || range, "order is an ordering for the ranged search: range is null");
     T5VQ_I_REQUIRE(compute_norms >= 0 && compute_norms <= 3, "compute_norms must be 0..3");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
     T5VQ_I_REQUIRE(D >= 64 && D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, 64 <= D <= 4096");
@@ -802,7 +810,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
 #define T5VQ_PREP(NCH_)                                                                                          \
     hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
                        x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se,  \
-                       static_cast<int>(D), n_list, tshare, row_blocks, zero, norm_x, norm_w)
+                       static_cast<int>(D), n_list, tshare, row_blocks, zero, norm_x, norm_w, order)
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }
@@ -836,7 +844,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv,                 \
         static_cast<int>(N), static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2),                    \
         static_cast<int>(splits), static_cast<int>(tiles_per_split), plain_map, c2, r, rg,                           \
-        static_cast<long long>(code_offset), ubuf, lbuf, cbuf, tshare
+        static_cast<long long>(code_offset), ubuf, lbuf, cbuf, tshare, order
     if (range)
         hipLaunchKernelGGL((filter_f16_kernel<true>), grid, dim3(THREADS), LDS_BYTES, stream, T5VQ_FILTER_ARGS);
     else
@@ -849,7 +857,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
                        dim3(COLLECT_THREADS), 0, stream,                                                             \
                        ubuf, lbuf, cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners),      \
                        exact_keys, rg, static_cast<long long>(code_offset), cnt, cand,                               \
-                       reinterpret_cast<long long*>(keys), tok_list, n_list)
+                       reinterpret_cast<long long*>(keys), tok_list, n_list, order)
     static_assert(4 * MAX_SPLITS <= 128, "collect_kernel: at most 64 lanes per token, two scanners each");
     if (scanners <= 4) { T5VQ_COLLECT(4, 1); }
     else if (scanners <= 8) { T5VQ_COLLECT(8, 1); }

@@ -18,8 +18,8 @@ struct T5vqZeroArgs {
     long long n[3];
 };
 extern "C" int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
-                                                  const int64_t* range, int64_t N, int64_t K, int64_t D,
-                                                  int64_t code_offset, int exact_keys, void* workspace,
+                                                  const int64_t* range, const int32_t* order, int64_t N, int64_t K,
+                                                  int64_t D, int64_t code_offset, int exact_keys, void* workspace,
                                                   int64_t workspace_bytes, int64_t* keys, int32_t* n_overflow,
                                                   T5vqZeroArgs zero, hipStream_t stream);
 

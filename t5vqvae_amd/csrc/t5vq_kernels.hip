@@ -502,10 +502,15 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ xx,
     const float* __restrict__ ee, const long long* __restrict__ range, int N, int K, int D, int n_splits,
     int tiles_per_split, long long code_offset, int atomic_merge, long long* __restrict__ keys,
-    SelfArgs self = SelfArgs{}) {
+    SelfArgs self = SelfArgs{}, const int* __restrict__ order = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = C::NT, BKC = C::BKC, ROW = C::ROW, CODE_TILE = C::CODE_TILE, G = C::G;
     constexpr int NLD = C::XV + C::WV;
+    // RANGED with `order` (a permutation of the token ids, t5vq_order_by_range): position p of the grid's token axis
+    // stands for token order[p] -- its row of x, its norm, its range, its key.  Tokens of one role are neighbours in
+    // `order`, so a token tile carries one or two ranges and skips the code tiles outside them, and nothing is moved
+    // in memory for it (a row is 3 KB contiguous wherever it lies).
+    auto token_at = [&](int p) { return (RANGED && order) ? order[p] : p; };
     static_assert(G >= 2 && NLD < 4 * NT, "interleave plan needs room");
     static_assert(!SELF || (D2 && !RANGED && BKC == 32 && C::F4_PER_ROW == 8), "SELF: plain search, staged two ahead");
     if (SELF) {   // every workgroup of the grid zeroes its slice of the statistics (before any early return)
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     for (int j = 0; j < C::XV; ++j) {
         int t = tok_base + s_row + C::ROWS_PER_PASS * j;
         if (t > N - 1) t = N - 1;
-        xp[j] = xg + static_cast<size_t>(t) * D + s_col;
+        xp[j] = xg + static_cast<size_t>(token_at(t)) * D + s_col;
     }
     gptr_t wpc[C::WV];
     gptr_t wpn[C::WV];
@@ -585,8 +590,8 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
     };
     const int st_off = s_row * ROW + s_col;   // + ROWS_PER_PASS * ROW * j
 
-    const int tok = tok_base + wave * 32 + l31;
-    const int tok_c = tok < N ? tok : N - 1;
+    const int tok = tok_base + wave * 32 + l31;   // position on the token axis; tok_c = the token it stands for
+    const int tok_c = token_at(tok < N ? tok : N - 1);
     float xv = (SELF && !xx) ? 0.f : xx[tok_c];   // SELF without given norms: set after the first code tile
     float xacc[SELF ? C::XV : 1][SELF ? 8 : 1];    // SELF: |x|^2 accumulators, [staged row j][chunk index mod 8]
     if (SELF) {
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
         tile_begin = tlo + split * per;
         tile_end = min(tile_begin + per, thi);
         if (tile_end <= tile_begin) {   // workgroup-uniform: nothing admissible for this workgroup
-            if (!atomic_merge && h == 0 && tok < N) keys[tok] = KEY_NONE;
+            if (!atomic_merge && h == 0 && tok < N) keys[tok_c] = KEY_NONE;
             return;
         }
     }
@@ -877,9 +882,9 @@ __global__ __launch_bounds__(256, C::MINW) void dist_mfma_v2_kernel(
         if (SELF) {
             keys[static_cast<size_t>(split) * N + tok] = key;   // one slot per (split, token): no prefill, no atomics
         } else if (atomic_merge) {
-            if (key != KEY_NONE) atomicMin(keys + tok, key);
+            if (key != KEY_NONE) atomicMin(keys + tok_c, key);
         } else {
-            keys[tok] = key;
+            keys[tok_c] = key;
         }
     }
 }
@@ -1034,10 +1039,59 @@ __global__ __launch_bounds__(256) void code_place_kernel(const long long* __rest
     if (valid) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
+// ---- tokens ordered by their code range (disentangled codebooks): a counting sort over (start tile, end tile) buckets.
+// Tokens of one role become neighbours, so a token tile of the search sees one or two ranges.  The granularity only
+// has to be fine enough for that: ranges that share a bucket merely share a tile's visit list.
+struct RangeBins {
+    long long code_offset;   // global id of the first code of this codebook (slice)
+    int K;                   // codes of this codebook (slice)
+    int shift;               // log2 of the bucket granularity in codes
+    int T;                   // buckets per axis: start in [0, T), end in [1, T]; bucket T (T + 1) = no admissible code
+};
+__host__ __device__ inline int range_bin_count(int T) { return T * (T + 1) + 1; }
+__device__ __forceinline__ int range_bucket(const long long* __restrict__ range, int i, const RangeBins& rb) {
+    long long a = range[2 * static_cast<size_t>(i)] - rb.code_offset;
+    long long e = range[2 * static_cast<size_t>(i) + 1] - rb.code_offset;
+    a = a < 0 ? 0 : (a > rb.K ? rb.K : a);
+    e = e < 0 ? 0 : (e > rb.K ? rb.K : e);
+    if (e <= a) return rb.T * (rb.T + 1);
+    const int st = static_cast<int>(a >> rb.shift);                           // < T (a < K)
+    const int et = static_cast<int>((e + (1LL << rb.shift) - 1) >> rb.shift); // 1 .. T
+    return st * (rb.T + 1) + et;
+}
+__global__ __launch_bounds__(256) void range_hist_kernel(const long long* __restrict__ range, int N, RangeBins rb,
+                                                         int* __restrict__ work) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < N;
+    const int b = valid ? range_bucket(range, i, rb) : 0;
+    int distinct;
+    const unsigned long long m = same_code_lanes(b, valid, &distinct);
+    if (valid && __ffsll(static_cast<long long>(m)) - 1 == lane) atomicAdd(work + b, __popcll(m));
+}
+__global__ __launch_bounds__(256) void range_place_kernel(const long long* __restrict__ range, int N, RangeBins rb,
+                                                          int* __restrict__ work, int* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < N;
+    const int b = valid ? range_bucket(range, i, rb) : 0;
+    int distinct;
+    const unsigned long long m = same_code_lanes(b, valid, &distinct);
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    int base = 0;
+    if (valid && leader == lane) base = atomicAdd(work + b, __popcll(m));
+    base = __shfl(base, leader < 0 ? lane : leader);
+    if (valid) order[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
 constexpr int GS_TOK = 64;    // tokens per workgroup (large N)
 constexpr int GS_TOK_SMALL = 16;   // ... when N / 64 workgroups would leave most CUs idle
+constexpr int GS_TOK_TINY = 4;     // ... one token per wave: a few thousand tokens still put two workgroups on every CU
+constexpr int GS_TINY_N = 8192;    // below this many tokens the tiny form is used
 constexpr int GS_SMALL_N = 32768;  // below this many tokens the small form is used (>= 2 workgroups per CU above)
-__host__ __device__ inline int gs_tok(long long N) { return N < GS_SMALL_N ? GS_TOK_SMALL : GS_TOK; }
+__host__ __device__ inline int gs_tok(long long N) {
+    return N < GS_TINY_N ? GS_TOK_TINY : (N < GS_SMALL_N ? GS_TOK_SMALL : GS_TOK);
+}
 
 // Wave 0 of a workgroup: group the workgroup's TOK tokens by code.  Group g = (s_gcode[g], member mask
 // s_gmask[g]); groups are numbered by their first member.  counts (nullable) receives every group's size.
@@ -1761,9 +1815,11 @@ int pick_nch(int64_t D) {
     return 0;
 }
 
-int g_dist_variant = 0;  // tuning knob (t5vq_set_tuning); 0 = default configuration
-int g_force_splits = 0;  // tuning knob: 0 = heuristic
-int g_depth2 = 1;        // tuning knob: staging registers double-buffered (loads two chunks ahead)
+// Tuning knobs (t5vq_set_tuning).  Per thread: a diagnostic call on one thread never changes what another
+// thread's launches pick, and nothing here is read and written concurrently.
+thread_local int g_dist_variant = 0;  // 0 = default configuration
+thread_local int g_force_splits = 0;  // 0 = heuristic
+thread_local int g_depth2 = 1;        // staging registers double-buffered (loads two chunks ahead)
 
 using CfgDefault = DistCfg<4, 32, false, 2>;
 using CfgSmall = DistCfg<2, 32, false, 2>;   // 128 x 64 tile: twice the workgroups when the problem cannot fill the chip
@@ -1845,6 +1901,7 @@ struct DistOpts {
     bool bounded = false;            // top-k pass: the range argument holds one excluded key per token
     const int* tok_list = nullptr;   // decision scan of the filtered search: device list of the tokens to search ...
     const int* n_listed = nullptr;   // ... and its length (device)
+    const int* order = nullptr;      // ranged search: the tokens in role order (t5vq_order_by_range); speed only
 };
 
 template <class C, bool V2 = false>
@@ -1910,13 +1967,13 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
     if (v2 && range && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
-                           T5VQ_DIST_ARGS, atomic, kp);
+                           T5VQ_DIST_ARGS, atomic, kp, SelfArgs{}, opts.order);
     } else if (v2 && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, true>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
     } else if (v2 && range) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, false>), grid, dim3(256), C::LDS_BYTES, stream,
-                           T5VQ_DIST_ARGS, atomic, kp);
+                           T5VQ_DIST_ARGS, atomic, kp, SelfArgs{}, opts.order);
     } else if (v2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, false, false>), grid, dim3(256), C::LDS_BYTES, stream,
                            T5VQ_DIST_ARGS, atomic, kp);
@@ -1997,6 +2054,7 @@ int launch_dist(const float* x, const float* w, const float* xx, const float* ee
 // is plain (no ranges), D % 256 == 0 and the tuning knobs are at their defaults.  With it a composite forward is
 // [distance + argmin] -> [gather + statistics] with nothing in front: C2 (N = 4096, K = 512) saves the row-norm /
 // preparation launch, its 4 us and the gap behind it.
+constexpr int64_t BUCKET_MIN_TOKENS = 1024;     // ranged search: from this many tokens on they are visited role by role
 constexpr int64_t SELF_MAX_KEY_SLOTS = 65536;   // splits x N never exceeds this for a problem the rule admits
 
 bool self_shape(int64_t N, int64_t K) {
@@ -2045,7 +2103,7 @@ int launch_dist_self(const float* x, const float* w, const float* xx, const floa
 // ================================================================================================
 extern "C" {
 
-int t5vq_version(void) { return 200; }
+int t5vq_version(void) { return 210; }
 int t5vq_set_tuning(int variant) {
     g_depth2 = variant >= 100000 ? 0 : 1;   // +100000: single staging register set
     variant %= 100000;
@@ -2085,11 +2143,14 @@ int t5vq_row_sqnorms_f32(const float* x, int64_t N, float* xx, const float* w, i
 }
 
 int t5vq_dist_argmin_f32(const float* x, const float* w, const float* xx, const float* ee, const int64_t* range,
-                         int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge, int64_t* keys,
-                         t5vq_stream_t stream) {
+                         const int32_t* order, int64_t N, int64_t K, int64_t D, int64_t code_offset, int merge,
+                         int64_t* keys, t5vq_stream_t stream) {
     T5VQ_REQUIRE(keys, "keys is null");
+    T5VQ_REQUIRE(!order || range, "order is an ordering for the ranged search: range is null");
+    DistOpts opts;
+    opts.order = order;
     return launch_dist(x, w, xx, ee, range, N, K, D, code_offset, merge, keys, nullptr,
-                       static_cast<hipStream_t>(stream));
+                       static_cast<hipStream_t>(stream), opts);
 }
 
 int t5vq_distances_f32(const float* x, const float* w, const float* xx, const float* ee, int64_t N, int64_t K,
@@ -2143,7 +2204,9 @@ static int launch_gather(const float* x, const float* w, const int64_t* keys, in
                        static_cast<int>(stats_begin), static_cast<int>(stats_count), counts, embed_sum, loss_partial, \
                        perm, key_sets)
 #define T5VQ_GS(NCH_, COS_)                                   \
-    if (gs_tok(N) == GS_TOK_SMALL) {                          \
+    if (gs_tok(N) == GS_TOK_TINY) {                           \
+        T5VQ_GS_T(NCH_, COS_, GS_TOK_TINY);                   \
+    } else if (gs_tok(N) == GS_TOK_SMALL) {                   \
         T5VQ_GS_T(NCH_, COS_, GS_TOK_SMALL);                  \
     } else {                                                  \
         T5VQ_GS_T(NCH_, COS_, GS_TOK);                        \
@@ -2196,6 +2259,42 @@ static int order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* per
                        perm);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
+}
+
+// Bucket granularity: 128 codes (the scan's code tile), doubled until the T (T + 1) + 1 buckets and the scan kernel's two
+// trailing words fit the K + 8 words every caller of the counting sort holds.
+static RangeBins plan_range_bins(int64_t K, int64_t code_offset) {
+    RangeBins rb;
+    rb.code_offset = code_offset;
+    rb.K = static_cast<int>(K);
+    rb.shift = 7;
+    for (;;) {
+        rb.T = static_cast<int>((K + (1LL << rb.shift) - 1) >> rb.shift);
+        if (static_cast<int64_t>(range_bin_count(rb.T)) + 2 <= K + 8) break;
+        ++rb.shift;
+    }
+    return rb;
+}
+
+static int order_by_range(const int64_t* range, int64_t N, int64_t K, int64_t code_offset, int32_t* order,
+                          int32_t* work, hipStream_t stream) {
+    T5VQ_REQUIRE(range && order && work, "null pointer");
+    T5VQ_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) && K < (1LL << 31) - 512, "N, K out of range");
+    const RangeBins rb = plan_range_bins(K, code_offset);
+    const int bins = range_bin_count(rb.T);
+    T5VQ_CHECK_HIP(hipMemsetAsync(work, 0, static_cast<size_t>(bins + 2) * 4, stream));
+    const dim3 grid(static_cast<unsigned>((N + 255) / 256));
+    const long long* rg = reinterpret_cast<const long long*>(range);
+    hipLaunchKernelGGL(range_hist_kernel, grid, dim3(256), 0, stream, rg, static_cast<int>(N), rb, work);
+    hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), bins);
+    hipLaunchKernelGGL(range_place_kernel, grid, dim3(256), 0, stream, rg, static_cast<int>(N), rb, work, order);
+    T5VQ_CHECK_HIP(hipGetLastError());
+    return T5VQ_OK;
+}
+
+int t5vq_order_by_range(const int64_t* range, int64_t N, int64_t K, int64_t code_offset, int32_t* order,
+                        int32_t* work, t5vq_stream_t stream) {
+    return order_by_range(range, N, K, code_offset, order, work, static_cast<hipStream_t>(stream));
 }
 
 int t5vq_reduce_partials_f32(const float* partials, int64_t n, float* loss_sum, t5vq_stream_t stream) {
@@ -2277,7 +2376,9 @@ int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t*
                        static_cast<int>(K), static_cast<int>(D), max_xx_bits, static_cast<int>(stats_begin),        \
                        static_cast<int>(stats_count), ep)
 #define T5VQ_FX_T(NCH_)                      \
-    if (tok == GS_TOK_SMALL) {               \
+    if (tok == GS_TOK_TINY) {                \
+        T5VQ_FX(NCH_, GS_TOK_TINY);          \
+    } else if (tok == GS_TOK_SMALL) {        \
         T5VQ_FX(NCH_, GS_TOK_SMALL);         \
     } else {                                 \
         T5VQ_FX(NCH_, GS_TOK);               \
@@ -2484,9 +2585,10 @@ struct FwdWorkspace {
         xx = align_up(8 * (self_shape(N, K) ? SELF_MAX_KEY_SLOTS : N), 16);   // fp32 [N]
         ee = align_up(xx + 4 * N, 16);                              // fp32 [padded(K)], 16-byte aligned
         partial = align_up(ee + 4 * t5vq_padded_codes(K), 16);      // fp32 [gather_blocks(N)], [N] with ordered tokens
-        perm = align_up(partial + 4 * N, 16);                       // int32 [N]: tokens ordered by code
-        work = align_up(perm + 4 * N, 16);                          // int32 [K + 2]: counting-sort cursors
-        total = align_up(work + 4 * (K + 2), 256);
+        perm = align_up(partial + 4 * N, 16);                       // int32 [N]: tokens in role order for the ranged
+                                                                    // search, then (rewritten) ordered by code
+        work = align_up(perm + 4 * N, 16);                          // int32 [K + 8]: counting-sort cursors
+        total = align_up(work + 4 * (K + 8), 256);
     }
 };
 }  // namespace
@@ -2537,6 +2639,15 @@ static int vq_forward_impl(const float* x, const float* w, const int64_t* range,
         if (rc != T5VQ_OK || !loss_sum) return rc;
         return t5vq_reduce_partials_f32(partial, t5vq_gather_blocks(N), loss_sum, stream);
     }
+    // Disentangled codebook, more than a few token tiles: visit the tokens role by role (a counting sort of the
+    // ranges; the order lives in the region the by-code ordering rewrites after the search).
+    const int32_t* role_order = nullptr;
+    if (range && N >= BUCKET_MIN_TOKENS) {
+        int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
+        const int rc0 = order_by_range(range, N, K, 0, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        if (rc0 != T5VQ_OK) return rc0;
+        role_order = p;
+    }
     PrepArgs prep{};
     prep.zero_a = counts;
     prep.n_a = counts ? K : 0;
@@ -2556,6 +2667,7 @@ static int vq_forward_impl(const float* x, const float* w, const int64_t* range,
     if (rc != T5VQ_OK) return rc;
     DistOpts opts;
     opts.keys_prefilled = true;
+    opts.order = role_order;
     rc = launch_dist(x, w, xx, ee, range, N, K, D, 0, 0, keys, nullptr, stream, opts);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
@@ -2675,8 +2787,15 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
         zero.p[2] = base + ws.work;
         zero.n[2] = K + 2;
     }
-    int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, N, K, D, 0, 0, base + ws.total,
-                                                filter_bytes, keys, n_overflow, zero, stream);
+    const int32_t* role_order = nullptr;
+    if (range && N >= BUCKET_MIN_TOKENS) {   // as in the scan form: tokens visited role by role
+        int32_t* p = reinterpret_cast<int32_t*>(base + ws.perm);
+        const int rc0 = order_by_range(range, N, K, 0, p, reinterpret_cast<int32_t*>(base + ws.work), stream);
+        if (rc0 != T5VQ_OK) return rc0;
+        role_order = p;
+    }
+    int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, role_order, N, K, D, 0, 0,
+                                                base + ws.total, filter_bytes, keys, n_overflow, zero, stream);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
     if (order) {

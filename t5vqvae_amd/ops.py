@@ -78,8 +78,35 @@ def row_sqnorms(x: Optional[torch.Tensor], w: Optional[torch.Tensor]):
     return xx, ee
 
 
-def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merge: bool = False):
-    """Packed (distance, index) keys [N] int64 of the nearest codeword per token."""
+def _check_order(order, ranges, n):
+    if order is None:
+        return
+    if ranges is None:
+        raise RuntimeError("order is an ordering for the ranged search: ranges is None")
+    _need(order, "order", torch.int32, 1)
+    if order.shape[0] != n:
+        raise RuntimeError(f"order must hold {n} token ids, got {order.shape[0]}")
+
+
+def order_by_range(ranges, k: int, code_offset: int = 0):
+    """int32 [N]: the token ids grouped by their (start, end) code range (t5vq_order_by_range) -- the visiting order
+    that lets every token tile of a ranged search skip the code tiles outside its one or two roles."""
+    lib = _lib.load()
+    _need(ranges, "ranges", torch.int64, 2)
+    n = ranges.shape[0]
+    if ranges.shape[1] != 2:
+        raise RuntimeError(f"ranges must be [N, 2], got {tuple(ranges.shape)}")
+    order = torch.empty(n, dtype=torch.int32, device=ranges.device)
+    work = torch.empty(k + 8, dtype=torch.int32, device=ranges.device)
+    with torch.cuda.device(ranges.device):
+        _lib.check(lib.t5vq_order_by_range(_p(ranges), n, k, code_offset, _p(order), _p(work), _stream(ranges)),
+                   "order_by_range")
+    return order
+
+
+def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merge: bool = False, order=None):
+    """Packed (distance, index) keys [N] int64 of the nearest codeword per token.  ``order`` (ranged search only):
+    the visiting order of the tokens (``order_by_range``); the keys do not depend on it."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
     n, d = x.shape
@@ -90,6 +117,7 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
         _need(ranges, "ranges", torch.int64, 2)
         if tuple(ranges.shape) != (n, 2):
             raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
+    _check_order(order, ranges, n)
     if keys is None:
         if merge:
             raise RuntimeError("merge=True needs existing keys")
@@ -97,17 +125,17 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
     else:
         _need(keys, "keys", torch.int64, 1)
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_f32(_p(x), _p(w), _p(xx), _p(ee), _p(ranges), n, k, d, code_offset,
+        _lib.check(lib.t5vq_dist_argmin_f32(_p(x), _p(w), _p(xx), _p(ee), _p(ranges), _p(order), n, k, d, code_offset,
                                             1 if merge else 0, _p(keys), _stream(x)), "dist_argmin")
     return keys
 
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True,
-                         ranges=None, code_offset: int = 0, return_norms: bool = False):
+                         ranges=None, code_offset: int = 0, return_norms: bool = False, order=None):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
     (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None (either or both): that norm is computed by the call's own
     first pass (no separate ``row_sqnorms``); a given norm is only read.  ``exact_keys=False``: only the index word is
-    guaranteed (cheaper).
+    guaranteed (cheaper).  ``order`` (ranged search only): the visiting order of the tokens (``order_by_range``).
     Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``; ``return_norms`` appends (xx, ee) -- the
     norms the search used, whether given or computed."""
     lib = _lib.load()
@@ -122,6 +150,7 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
         _need(ranges, "ranges", torch.int64, 2)
         if tuple(ranges.shape) != (n, 2):
             raise RuntimeError(f"ranges must be [{n}, 2], got {tuple(ranges.shape)}")
+    _check_order(order, ranges, n)
     # compute_norms of the C ABI: 0 both given, 1 both computed (outputs), 2 xx given / ee computed, 3 the reverse.
     # A norm that is not given is allocated here and written by the search's first pass; a given one is an input and
     # is never overwritten.
@@ -141,7 +170,7 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges),
+        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges), _p(order),
                                                      n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
                                                      _p(keys), _p(ovf), _stream(x)), "dist_argmin_filtered")
     out = (keys, ovf) if want_overflow else (keys,)

@@ -24,7 +24,9 @@ import torch
 from torch import nn
 
 from . import ops
-from .roles import INDEX_MODES, bucket_by_role
+from .roles import INDEX_MODES
+
+BUCKET_MIN_TOKENS = 1024     # ranged search: tokens are visited role by role from this many on (= the library's rule)
 
 _KEY_NONE = 0x7FFFFFFFFFFFFFFF
 # per-module state of the search="auto" back-off (events and pinned buffers: kept out of the module's __dict__ so
@@ -133,7 +135,8 @@ class _QuantizerBase(nn.Module):
         if self.loss not in ops.LOSS_KINDS:
             exit("Error: wrong loss name")                   # reference: vqvae/vqvae.py:67,155 (SystemExit)
 
-    bucket_roles = True          # disentangled mode: visit tokens role by role (see _nearest_keys)
+    bucket_roles = True          # disentangled mode: visit tokens role by role (see _nearest_keys); False is a
+    #                              diagnostic (tools/bench_ranged.py) and takes the fine-grained entry points
     # How the nearest code is found.  "scan": fused fp32 MFMA distance + argmin over all codes.  "filter": an fp16
     # MFMA pass with a proven error bound leaves the few codes that can be the fp32 argmin and the scan's fp32
     # arithmetic decides among them -- the SAME indices, bit for bit, several times faster on large problems.
@@ -153,31 +156,26 @@ class _QuantizerBase(nn.Module):
     def _nearest_keys(self, x, w, ranges, code_offset=0, xx=None, exact_keys=True, use_filter=None):
         """Packed (distance, index) keys of the nearest admissible codeword per token.
 
-        Disentangled mode with many tokens: tokens are first bucketed by their [start, end) range (a stable
-        argsort of N int64 and one row permutation -- data movement only), so that each 128-token tile of the
+        Disentangled mode with many tokens: the search visits the tokens role by role (``ops.order_by_range``: a
+        counting sort of the [start, end) ranges on the device; no row of x is moved), so that each token tile of the
         distance kernel carries (mostly) one role and skips every code tile outside it: a grouped codebook then
-        costs 2 D sum_r N_r K_r flops instead of 2 D N K.  Keys are scattered back to token order."""
+        costs 2 D sum_r N_r K_r flops instead of 2 D N K.  Keys come out in token order either way."""
         if self.index_mode not in INDEX_MODES:
             raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
         if use_filter is None:
             use_filter = self._use_filter(x, w, ranges)
         ee = self._code_norms(w)             # cached |e|^2 of this codebook, or None
-        if ranges is None or not self.bucket_roles or x.shape[0] < 1024:
-            if use_filter:
-                # norms that are not given are written by the search's own first pass (bit-identical to row_sqnorms)
-                return self._filtered_keys(x, w, exact_keys or code_offset != 0, ranges, code_offset, xx=xx, ee=ee)
-            if xx is None or ee is None:
-                xx_, ee_ = ops.row_sqnorms(x if xx is None else None, w if ee is None else None)
-                xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
-            return ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset)
-        order, rs = bucket_by_role(ranges)
-        xs = x.index_select(0, order)
+        order = None
+        if ranges is not None and self.bucket_roles and x.shape[0] >= BUCKET_MIN_TOKENS:
+            order = ops.order_by_range(ranges, w.shape[0], code_offset)
         if use_filter:
-            ks = self._filtered_keys(xs, w, exact_keys or code_offset != 0, rs, code_offset, ee=ee)
-        else:
-            xx, ee_ = ops.row_sqnorms(xs, w if ee is None else None)
-            ks = ops.dist_argmin(xs, w, xx, ee_ if ee is None else ee, rs, code_offset=code_offset)
-        return torch.empty_like(ks).index_copy_(0, order, ks)
+            # norms that are not given are written by the search's own first pass (bit-identical to row_sqnorms)
+            return self._filtered_keys(x, w, exact_keys or code_offset != 0, ranges, code_offset, xx=xx, ee=ee,
+                                       order=order)
+        if xx is None or ee is None:
+            xx_, ee_ = ops.row_sqnorms(x if xx is None else None, w if ee is None else None)
+            xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
+        return ops.dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, order=order)
 
     # --- |e|^2 kept between calls ------------------------------------------------------------------------
     code_norm_cache = True       # False: recompute the codebook norms in every call, as the reference does (:107)
@@ -229,9 +227,9 @@ class _QuantizerBase(nn.Module):
             return False
         return True
 
-    def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0, xx=None, ee=None):
+    def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0, xx=None, ee=None, order=None):
         keys, ovf = ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, want_overflow=True, exact_keys=exact_keys,
-                                             ranges=ranges, code_offset=code_offset)
+                                             ranges=ranges, code_offset=code_offset, order=order)
         self._note_unsettled(ovf, x.shape[0])
         return keys
 
@@ -258,8 +256,12 @@ class _QuantizerBase(nn.Module):
         """Order the kernels of one call (single GPU, or token-sharded when ``plan.group`` is set).
 
         Single GPU, whole-codebook search: ONE op, t5vq::vq_step (forward + finalize).  Token-sharded: t5vq::vq_forward,
-        ONE all-reduce of the statistics head [embed_sum | counts | loss_sum], t5vq::vq_finalize.  Role-bucketed
-        search and the order-independent statistics chain the fine-grained entry points."""
+        ONE all-reduce of the statistics head [embed_sum | counts | loss_sum], t5vq::vq_finalize.  Disentangled
+        codebooks go the same way (the composite forward orders the tokens by role itself, on the device); only
+        ``index_mode="absolute"``, the diagnostic ``bucket_roles=False`` and the order-independent statistics chain the
+        fine-grained entry points."""
+        if self.index_mode not in INDEX_MODES:
+            raise ValueError(f"index_mode must be one of {INDEX_MODES}, got {self.index_mode!r}")
         n, d = x.shape
         k = w.shape[0]
         dev = x.device
@@ -267,7 +269,10 @@ class _QuantizerBase(nn.Module):
         mse = plan.loss == "mse"
         fixed = update and self.deterministic
         use_filter = self._use_filter(x, w, ranges)
-        bucketed = ranges is not None and ((self.bucket_roles and n >= 1024) or self.index_mode == "absolute")
+        # the composite forward visits a ranged batch role by role from BUCKET_MIN_TOKENS on: switching that off, or
+        # shifting the indices by their range start, needs the keys between the search and the gather
+        bucketed = ranges is not None and ((not self.bucket_roles and n >= BUCKET_MIN_TOKENS)
+                                           or self.index_mode == "absolute")
 
         n_total, batch, world = n, plan.batch, 1
         if plan.group is not None:
@@ -305,7 +310,7 @@ class _QuantizerBase(nn.Module):
             if ovf is not None:
                 self._note_unsettled(ovf, n)
         else:
-            # role-bucketed search (permute, search, scatter back; scan or filter), then the fine-grained calls
+            # the search on its own (scan or filter), the keys adjusted, then the fine-grained calls
             stats = torch.empty(terms_off + n_terms, dtype=torch.float32, device=dev)
             ste = torch.empty_like(x)
             idx = torch.empty(n, dtype=torch.int64, device=dev)

@@ -38,7 +38,13 @@ def _pack(d, idx):
     return (s << 32) | (idx.to(torch.int64) & 0xFFFFFFFF)
 
 
-def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False):
+def order_by_range(ranges, k, code_offset=0):
+    """A visiting order only: any permutation gives the same keys."""
+    return torch.argsort(ranges[:, 0] * (1 << 32) + ranges[:, 1], stable=True).to(torch.int32)
+
+
+def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False, order=None):
+    assert order is None or (ranges is not None and sorted(order.tolist()) == list(range(x.shape[0])))
     k = w.shape[0]
     d = (xx.unsqueeze(1) + ee[:k]) - 2 * (x @ w.t())
     gid = torch.arange(k).unsqueeze(0) + code_offset
@@ -66,10 +72,10 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
 
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True, ranges=None,
-                         code_offset=0):
+                         code_offset=0, order=None):
     xx_, ee_ = row_sqnorms(x, w)
     xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
-    out = dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, keys=keys)
+    out = dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, keys=keys, order=order)
     return (out, torch.zeros(1, dtype=torch.int32)) if want_overflow else out
 
 

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
     assert lib.t5vq_version() >= 100
     assert lib.t5vq_padded_codes(10000) == 10112 and lib.t5vq_padded_codes(128) == 128
-    assert lib.t5vq_gather_blocks(65) == 5 and lib.t5vq_gather_blocks(65536) == 1024   # 16 / 64 tokens per workgroup
+    assert lib.t5vq_gather_blocks(65) == 17 and lib.t5vq_gather_blocks(10000) == 625 \
+        and lib.t5vq_gather_blocks(65536) == 1024                                    # 4 / 16 / 64 tokens per workgroup
 
 
 def test_invalid_arguments_are_rejected_before_any_launch():
@@ -37,7 +38,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.t5vq_row_sqnorms_f32(p, 4, p, p, 4, p, 6, None) == 1          # D % 4 != 0
     assert b"multiple of 4" in lib.t5vq_last_error()
-    assert lib.t5vq_dist_argmin_f32(None, p, p, p, None, 4, 4, 8, 0, 0, p, None) == 1
+    assert lib.t5vq_dist_argmin_f32(None, p, p, p, None, None, 4, 4, 8, 0, 0, p, None) == 1
     assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 8, 7, None, None, None, None, 0, 4, None, None, None, None,
                                      None) == 1
     assert lib.t5vq_gather_stats_f32(p, p, p, 4, 4, 4096, 0, None, None, None, None, 0, 4, None, None, None,

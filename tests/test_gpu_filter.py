@@ -187,6 +187,27 @@ def test_filtered_keys_identical_to_scan_with_role_ranges(n, k, d, offset):
         assert torch.equal((scan & 0xFFFFFFFF)[~none], (fidx & 0xFFFFFFFF)[~none])
     assert int(none.sum()) > 0                               # the empty / missing ranges were exercised
 
+    # the same searches told to VISIT the tokens role by role (t5vq_order_by_range) instead of being handed permuted
+    # rows: x, xx, ranges and keys stay in token order, the keys must not change -- nor with any other permutation
+    xx, ee = ops.row_sqnorms(x, w)
+    scan = ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset)
+    dev_order = ops.order_by_range(rg, k, offset)
+    assert dev_order.dtype == torch.int32
+    assert torch.equal(torch.sort(dev_order.long()).values, torch.arange(n, device="cuda"))
+    a = (rg[:, 0] - offset).clamp(0, k)
+    e = (rg[:, 1] - offset).clamp(0, k)
+    t = (k + 127) // 128                                     # these K keep the 128-code granularity
+    bucket = torch.where(e > a, (a // 128) * (t + 1) + (e + 127) // 128, torch.full_like(a, t * (t + 1)))
+    assert bool((bucket[dev_order.long()].diff() >= 0).all())   # tokens of one (start, end) bucket are neighbours
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for order in (dev_order, torch.randperm(n, device="cuda", generator=g).to(torch.int32)):
+        assert torch.equal(ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset, order=order), scan)
+        assert torch.equal(ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg, code_offset=offset, order=order), scan)
+        keys2, xx2, ee2 = ops.dist_argmin_filtered(x, w, ranges=rg, code_offset=offset, order=order, return_norms=True)
+        assert torch.equal(keys2, scan) and torch.equal(xx2, xx) and torch.equal(ee2, ee)   # norms land by token
+    with pytest.raises(RuntimeError):
+        ops.dist_argmin(x, w, xx, ee, None, order=dev_order)        # an order without ranges is a caller's mistake
+
 
 def test_disentangled_module_filter_equals_scan():
     from t5vqvae_amd import VectorQuantizerEMA

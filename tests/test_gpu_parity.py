@@ -84,7 +84,8 @@ def test_disentangled_straddling_ranges():
 
 
 def test_disentangled_bucketed_equals_unbucketed_and_oracle():
-    """N >= 1024 takes the role-bucketed route (token permutation + code-tile skipping)."""
+    """N >= 1024 takes the role-ordered route (tokens visited role by role on the device + code-tile skipping);
+    bucket_roles=False takes the fine-grained entry points in token order."""
     k, d, n = 2048, 768, 3000
     roles = [(0, 256), (256, 512), (512, 1024), (1024, 1100), (1100, 2048), (100, 1500)]
     x = synth.normal((1, n, d), 16, 0)

@@ -178,8 +178,14 @@ def test_two_ranks_on_one_gpu_gloo(mode):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(240)
-        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    try:
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    finally:
+        for p in procs:              # a worker stuck in a collective must not outlive the test holding the GPU
+            if p.is_alive():
+                p.kill()
+                p.join(10)
     res = dict(q.get(timeout=5) for _ in range(2))
     assert max(res.values()) <= TOL, res
