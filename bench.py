@@ -185,6 +185,36 @@ def per_call_ms(mod, x, w, ema_w, cs, iters):
     return statistics.median(ts), min(ts), out
 
 
+def graph_replay_ms(mod, x, w, ema_w, cs, iters):
+    """The per-call protocol with the call captured once in a HIP graph and replayed: what a caller sees who takes the
+    host's enqueue work (Python, dispatcher, one hipLaunchKernel per node) out of a launch-bound step.  Same kernels,
+    same state reset outside the timed region, HIP events around the replay.  (median, min) in ms."""
+    import torch
+    ts = []
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
+            for _ in range(3):
+                mod(x)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            mod(x)
+        for i in range(iters + 3):
+            mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1))
+    del graph
+    return statistics.median(ts), min(ts)
+
+
 # =====================================================================================================
 # CPU leg: the oracle as baseline and as checker (the ONLY place that imports oracle/)
 # =====================================================================================================
@@ -321,6 +351,11 @@ def single_gpu_configs(args, dev):
             b2b = back_to_back_ms(mod, x, w, ema_w, cs, 2 * args.config_iters)
             entry["ms_back_to_back"] = b2b
             entry["frac_of_mfma_roofline_back_to_back"] = (2.0 * n * k * d / PEAK_FP32_MFMA_TFLOPS / 1e12) / (b2b * 1e-3)
+        if wl in ("c1", "c2"):            # launch-bound shapes: the same call replayed from a captured HIP graph
+            gmed, gmin = graph_replay_ms(mod, x, w, ema_w, cs, args.config_iters)
+            entry["ms_per_call_graph_replay_median"] = gmed
+            entry["ms_per_call_graph_replay_min"] = gmin
+            entry["frac_of_mfma_roofline_graph_replay"] = (2.0 * n * k * d / PEAK_FP32_MFMA_TFLOPS / 1e12) / (gmed * 1e-3)
         if not args.no_cpu_baseline:
             leg = cpu_leg(k, d, update, args.search, state, dev, 2880 if wl == "c1" else 4096, 0.0, desc)
             entry["parity"] = leg["parity"]
