@@ -59,7 +59,10 @@ def test_noalloc_forward_equals_workspace_forward_twice():
     d = 768
     # first call: enough tokens for the ordered statistics walk (every region of the scratch is used);
     # second call: smaller N AND smaller K, the ranged search, no token ordering -- over the first call's leftovers
-    cases = [(40000, 1000, None), (1500, 300, [(0, 100), (100, 300), (20, 250)])]
+    # third call: ranged AND ordered walk -- the token-order region holds the role order during the search and is
+    # rewritten with the by-code order for the statistics kernel
+    cases = [(40000, 1000, None), (1500, 300, [(0, 100), (100, 300), (20, 250)]),
+             (36000, 900, [(0, 300), (300, 900), (100, 500)])]
     for i, (n, k, roles) in enumerate(cases):
         x = synth.normal((n, d), 70 + i, 0).to(dev)
         w = synth.normal((k, d), 70 + i, 1).to(dev)

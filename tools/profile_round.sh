@@ -19,18 +19,23 @@ stats() {  # name, then the program and its arguments
   local f
   f=$(find "$OUT/trace_$name" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv"
+  python3 "$ROOT/tools/trace_by_grid.py" "$OUT/trace_$name" > "$OUT/${TAG}_${name}_kernels_by_grid.csv"
   echo "trace $name ok"
 }
-pmc() {  # name, workload, counters...
+pmc() {  # name, workload, counters...   (T5VQ_PROF_SEARCH=filter: the filtered step instead of the scan)
   local name=$1 wl=$2; shift 2
   rm -rf "$OUT/pmc_$name"
-  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$ROOT/tools/run_kernels.py" "$wl" 3 step scan \
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$ROOT/tools/run_kernels.py" "$wl" 3 step ${T5VQ_PROF_SEARCH:-scan} \
       > "$OUT/pmc_${name}.log" 2>&1 || { echo "pmc $name failed"; tail -3 "$OUT/pmc_${name}.log"; return 1; }
   echo "pmc $name ok"
 }
 
 stats bench python3 "$ROOT/bench.py" || exit 1
 grep "^{" "$OUT/bench_stdout.txt" | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+# the headline shape alone (no per-configuration table, no series point, no parity slice): every launch of the fused
+# distance + argmin kernel in this run is the C3 shape, so the per-symbol average is the roofline's kernel time
+stats c3_headline python3 "$ROOT/bench.py" --workload c3 --no-configs --no-cpu-baseline || exit 1
+grep "^{" "$OUT/c3_headline_stdout.txt" | tail -1 > "$OUT/${TAG}_c3_headline_under_rocprof.json"
 for wl in c1 c2 c4; do
   stats $wl python3 "$ROOT/tools/run_kernels.py" $wl 20 step scan || exit 1
   pmc ${wl}_fetch $wl FETCH_SIZE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES || exit 1
@@ -38,6 +43,13 @@ for wl in c1 c2 c4; do
 done
 pmc c3_fetch c3 FETCH_SIZE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES || exit 1
 pmc c3_write c3 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 1
+# clocks and matrix-pipe occupancy in cycles (the fp16 filter runs power-limited: its time-based share of the nominal peak
+# understates what the pipe does per cycle), scan and filtered step at C3; kernel statistics of the filtered step
+pmc c3_clock c3 GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES || exit 1
+T5VQ_PROF_SEARCH=filter pmc c3_filter_clock c3 GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE || exit 1
+T5VQ_PROF_SEARCH=filter pmc c3_filter_fetch c3 FETCH_SIZE || exit 1
+stats c3_filter python3 "$ROOT/tools/run_kernels.py" c3 20 step filter || exit 1
+{ echo "== c3 scan step: clocks =="; python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_c3_clock"; echo "== c3 filtered step: clocks, LDS, fetch =="; python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_c3_filter_clock"; python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_c3_filter_fetch"; } > "$OUT/${TAG}_c3_clocks_pmc_summary.txt" 2>&1
 for wl in c1 c2 c3 c4; do
   { echo "== $wl: rocprofv3 --pmc, mean per launch (tools/pmc_summary.py) =="; python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_${wl}_fetch"; python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_${wl}_write"; } > "$OUT/${TAG}_${wl}_pmc_summary.txt" 2>&1
 done
