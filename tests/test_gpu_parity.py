@@ -104,6 +104,39 @@ def test_disentangled_bucketed_equals_unbucketed_and_oracle():
         check_step(m, st, xt, srl_t, disent=True)
 
 
+@pytest.mark.parametrize("k,offset", [(5, 0), (100, 0), (129, 7), (5000, 0), (65536, 0), (40000, 65536)])
+def test_role_order_is_a_permutation_for_any_codebook_size(k, offset):
+    """t5vq_order_by_range over codebook sizes on both sides of every bucket-granularity step (K < 128: one bucket
+    per axis; K = 65536: 512-code buckets), random ranges incl. empty ones, ones beyond the codebook and ones before
+    its first code (a code shard): always a permutation of the token ids, tokens of one (start bucket, end bucket)
+    pair neighbours; the ranged search gives the same keys with it as without."""
+    from t5vqvae_amd import ops
+    n, d = 3000, 64
+    g = torch.Generator().manual_seed(k)
+    a = torch.randint(-50, k + 50, (n,), generator=g)
+    b = a + torch.randint(-3, max(k // 2, 4), (n,), generator=g)
+    table = torch.tensor([[0, k], [0, max(k // 3, 1)], [k // 2, k], [k + 1, k + 9]])
+    pick = torch.randint(0, 4, (n,), generator=g)
+    rg = torch.where((torch.arange(n) % 3 == 0).unsqueeze(1), torch.stack([a, b], 1), table[pick]) + offset
+    rg = rg.clamp_min(0).contiguous().cuda()
+    order = ops.order_by_range(rg, k, offset)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device="cuda"))
+    shift = 7
+    while ((k + (1 << shift) - 1) >> shift) * (((k + (1 << shift) - 1) >> shift) + 1) + 3 > k + 8:
+        shift += 1
+    t = (k + (1 << shift) - 1) >> shift
+    lo, hi = (rg[:, 0] - offset).clamp(0, k), (rg[:, 1] - offset).clamp(0, k)
+    bucket = torch.where(hi > lo, (lo >> shift) * (t + 1) + ((hi + (1 << shift) - 1) >> shift),
+                         torch.full_like(lo, t * (t + 1)))
+    assert bool((bucket[order.long()].diff() >= 0).all())
+    if k <= 5000:
+        w = synth.normal((k, d), 31, 0, device="cuda")
+        x = synth.normal((n, d), 32, 0, device="cuda")
+        xx, ee = ops.row_sqnorms(x, w)
+        plain = ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset)
+        assert torch.equal(ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset, order=order), plain)
+
+
 def test_cosine_loss_vs_oracle():
     m, st = make_ema(512, 768, 9, loss="cosine")
     check_step(m, st, synth.normal((4, 26, 768), 10, 0), loss="cosine")
