@@ -46,6 +46,7 @@ WORKLOADS = {
     "c4": (131072, 16384, 768, True, "C4 share N=2^20/8 per GPU K=16384 D=768 fused fwd+EMA"),
 }
 C4_TOTAL_TOKENS = 1 << 20
+WARMUP_CALLS = 5          # untimed calls in front of every per-call series (>= 20 iterations after >= 5 warm-ups)
 C5_TOKENS, C5_CODES = 65536, 65536
 
 
@@ -172,7 +173,7 @@ def per_call_ms(mod, x, w, ema_w, cs, iters):
     import torch
     ts = []
     with torch.no_grad():
-        for i in range(iters + 3):
+        for i in range(iters + WARMUP_CALLS):
             mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -180,7 +181,7 @@ def per_call_ms(mod, x, w, ema_w, cs, iters):
             out = mod(x)
             e1.record()
             torch.cuda.synchronize()
-            if i >= 3:
+            if i >= WARMUP_CALLS:
                 ts.append(e0.elapsed_time(e1))
     return statistics.median(ts), min(ts), out
 
@@ -201,7 +202,7 @@ def graph_replay_ms(mod, x, w, ema_w, cs, iters):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             mod(x)
-        for i in range(iters + 3):
+        for i in range(iters + WARMUP_CALLS):
             mod._embedding.weight.copy_(w), mod._ema_w.copy_(ema_w), mod._ema_cluster_size.copy_(cs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -209,7 +210,7 @@ def graph_replay_ms(mod, x, w, ema_w, cs, iters):
             graph.replay()
             e1.record()
             torch.cuda.synchronize()
-            if i >= 3:
+            if i >= WARMUP_CALLS:
                 ts.append(e0.elapsed_time(e1))
     del graph
     return statistics.median(ts), min(ts)
@@ -304,7 +305,7 @@ def c5_shard_config(dev, search, iters, check):
 
     ts = []
     with torch.no_grad():
-        for i in range(iters + 3):
+        for i in range(iters + WARMUP_CALLS):
             cs.copy_(cs0), ew.copy_(ew0), wl.copy_(w)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -312,7 +313,7 @@ def c5_shard_config(dev, search, iters, check):
             keys = call()
             e1.record()
             torch.cuda.synchronize()
-            if i >= 3:
+            if i >= WARMUP_CALLS:
                 ts.append(e0.elapsed_time(e1))
     med = statistics.median(ts)
     out = {"name": "c5_shard", "workload": f"one code shard of C5: {kl} of {k} codes (code_offset {off}), N={n} tokens, "
@@ -750,7 +751,7 @@ def main():
     ap.add_argument("--regime", default="uniform", choices=["uniform", "cold", "collapsed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration table of the one-GPU run")
-    ap.add_argument("--config-iters", type=int, default=10)
+    ap.add_argument("--config-iters", type=int, default=20, help="timed calls per entry of the per-call protocol")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU + gloo + a test stand-in for the kernels: exercises the launcher and the collectives only")
     ap.add_argument("--search", default="scan", choices=["scan", "filter", "auto"],
