@@ -389,29 +389,34 @@ def test_composite_calls_equal_fine_grained(n, k, d, ranged, loss):
     assert torch.equal(sc_e[:2], sc_b[:2]) and float(sc_e[2]) == 0.0
 
 
-def test_module_step_replays_from_a_hip_graph():
+@pytest.mark.parametrize("disent", [False, True])
+def test_module_step_replays_from_a_hip_graph(disent):
     """The C ABI only enqueues on the stream it is given and allocates nothing, so a whole training-mode call can be
-    captured once into a HIP graph and replayed: the replayed steps equal eager steps on a twin module."""
+    captured once into a HIP graph and replayed: the replayed steps equal eager steps on a twin module.  The
+    disentangled form (N >= 1024) also orders the tokens by role inside the captured call."""
     n, k, d = 2880, 1000, 768
-    m1, st = make_ema(k, d, 11)
-    m2, _ = make_ema(k, d, 11)
+    m1, st = make_ema(k, d, 11, disentanglement=disent)
+    m2, _ = make_ema(k, d, 11, disentanglement=disent)
     m1.encodings = m2.encodings = "indices"
     x = synth.normal((n, d), 12, 0, device="cuda").view(64, 45, d)
+    srl = None
+    if disent:
+        srl = synth.role_ranges(n, [(0, 300), (300, 1000), (100, 600)], 12, 1, device="cuda").view(64, 45, 2)
     xs = x.clone()
     with torch.no_grad():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            m1(xs)                                  # warm-up call outside the capture (first-launch set-up)
+            m1(xs, srl)                             # warm-up call outside the capture (first-launch set-up)
         torch.cuda.current_stream().wait_stream(side)
-        m2(x)
+        m2(x, srl)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = m1(xs)
+            out = m1(xs, srl)
         for step in range(3):
             xs.copy_(x * (1.0 + 0.1 * step))
             g.replay()
-            ref = m2(x * (1.0 + 0.1 * step))
+            ref = m2(x * (1.0 + 0.1 * step), srl)
             torch.cuda.synchronize()
             assert torch.equal(out[3], ref[3])
             # embed_sum is accumulated with float atomics, so the two codebooks agree to rounding, not bitwise
