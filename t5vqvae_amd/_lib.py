@@ -67,6 +67,9 @@ _lib = None
 _torch_ops = None
 
 
+ABI_VERSION = 210     # t5vq_version() of the library these signatures were written against (the `order` arguments)
+
+
 class T5VQError(RuntimeError):
     pass
 
@@ -85,6 +88,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # a library older than these signatures would be called with shifted arguments: refuse it instead
+    if int(lib.t5vq_version()) < ABI_VERSION:
+        raise T5VQError(f"{LIB_PATH} is version {int(lib.t5vq_version())}, this binding needs >= {ABI_VERSION}: "
+                        "rebuild it (`make -C t5vqvae_amd/csrc all`)")
     _lib = lib
     return lib
 
