@@ -33,6 +33,11 @@ inline const Tensor& need(const Tensor& t, const char* name, at::ScalarType dtyp
     TORCH_CHECK(ndim < 0 || t.dim() == ndim, name, " must have ", ndim, " dims, got shape ", t.sizes());
     return t;
 }
+// every tensor of a call lives on the device of its first one: a pointer into another GPU's memory would fault there
+inline void same_device(const Tensor& ref, const OptTensor& t, const char* name) {
+    if (t.has_value() && t->defined())
+        TORCH_CHECK(t->device() == ref.device(), name, " is on ", t->device(), ", expected ", ref.device());
+}
 template <class T = float>
 inline T* ptr(const OptTensor& t) { return t.has_value() && t->defined() ? static_cast<T*>(t->data_ptr()) : nullptr; }
 
@@ -74,6 +79,7 @@ Fwd forward_impl(const Tensor& x, const Tensor& w, const OptTensor& ranges, cons
     if (xx.has_value()) TORCH_CHECK(need(*xx, "xx").numel() == N, "xx must hold ", N, " row norms");
     if (ee.has_value()) TORCH_CHECK(need(*ee, "ee").numel() == t5vq_padded_codes(K), "ee must be the padded |e|^2 buffer");
     if (filtered) TORCH_CHECK(D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, D <= 4096");
+    same_device(x, w, "w"), same_device(x, ranges, "ranges"), same_device(x, xx, "xx"), same_device(x, ee, "ee");
     const auto f32 = x.options();
     Fwd r;
     r.ste = at::empty_like(x);
@@ -119,6 +125,8 @@ Tensor finalize_impl(const OptTensor& cs, const OptTensor& ema_w, const OptTenso
                     "state tensors do not match (K, D)");
     }
     if (ee_out.has_value()) TORCH_CHECK(need(*ee_out, "ee_out").numel() >= K, "ee_out must hold at least K norms");
+    same_device(stats, cs, "cluster_size"), same_device(stats, ema_w, "ema_w"), same_device(stats, w, "w");
+    same_device(stats, ee_out, "ee_out");
     Tensor scalars = at::empty({4}, stats.options());
     const float* sp = stats.data_ptr<float>();
     ok(t5vq_vq_ema_finalize_f32(update ? ptr(cs) : nullptr, update ? ptr(ema_w) : nullptr, update ? ptr(w) : nullptr,
@@ -177,6 +185,9 @@ Tensor ste_backward(const OptTensor& g_out, const Tensor& diff, const OptTensor&
     OptTensor go = g_out, gl = g_loss;
     if (go.has_value()) go = need(go->contiguous(), "g_out");
     if (gl.has_value()) gl = need(gl->contiguous(), "g_loss");
+    TORCH_CHECK(!go.has_value() || go->numel() == diff.numel(), "g_out must have diff's element count");
+    TORCH_CHECK(!gl.has_value() || gl->numel() == 1, "g_loss must be a scalar");
+    same_device(diff, go, "g_out"), same_device(diff, gl, "g_loss");
     Tensor out = at::empty_like(diff);
     ok(t5vq_ste_backward_f32(ptr(go), diff.data_ptr<float>(), ptr(gl), static_cast<float>(coef), diff.numel(),
                              out.data_ptr<float>(), stream_of(diff)),
@@ -190,6 +201,9 @@ Tensor scatter_rows(const Tensor& rows, const Tensor& idx, const OptTensor& scal
     need(rows, "rows", at::kFloat, 2), need(idx, "idx", at::kLong);
     OptTensor sd = scale_dev;
     if (sd.has_value()) sd = need(sd->contiguous(), "scale_dev");
+    TORCH_CHECK(K > 0 && idx.numel() == rows.size(0), "idx must hold one code per row, K must be positive");
+    TORCH_CHECK(!sd.has_value() || sd->numel() == 1, "scale_dev must be a scalar");
+    same_device(rows, idx, "idx"), same_device(rows, sd, "scale_dev");
     Tensor out = at::empty({K, rows.size(1)}, rows.options());
     ok(t5vq_scatter_rows_f32(rows.data_ptr<float>(), idx.data_ptr<int64_t>(), ptr(sd), static_cast<float>(scale_host),
                              rows.size(0), K, rows.size(1), out.data_ptr<float>(), stream_of(rows)),
@@ -204,6 +218,10 @@ std::tuple<Tensor, OptTensor> cosine_backward(const Tensor& x, const Tensor& q, 
     OptTensor go = g_out, gl = g_loss;
     if (go.has_value()) go = need(go->contiguous(), "g_out");
     if (gl.has_value()) gl = need(gl->contiguous(), "g_loss");
+    TORCH_CHECK(q.sizes() == x.sizes(), "x and q must have the same shape");
+    TORCH_CHECK(!go.has_value() || go->numel() == x.numel(), "g_out must have x's element count");
+    TORCH_CHECK(!gl.has_value() || gl->numel() == 1, "g_loss must be a scalar");
+    same_device(x, q, "q"), same_device(x, go, "g_out"), same_device(x, gl, "g_loss");
     Tensor gx = at::empty_like(x);
     OptTensor gq;
     if (want_grad_q) gq = at::empty_like(x);
@@ -220,6 +238,7 @@ Tensor distances(const Tensor& x, const Tensor& w) {
     need(x, "x", at::kFloat, 2), need(w, "w", at::kFloat, 2);
     const int64_t N = x.size(0), D = x.size(1), K = w.size(0);
     TORCH_CHECK(w.size(1) == D, "x and w disagree on D");
+    same_device(x, w, "w");
     Tensor xx = at::empty({N}, x.options()), ee = at::empty({t5vq_padded_codes(K)}, x.options());
     Tensor out = at::empty({N, K}, x.options());
     void* stream = stream_of(x);
@@ -235,6 +254,7 @@ Tensor distances(const Tensor& x, const Tensor& w) {
 Tensor one_hot(const Tensor& idx, int64_t K) {
     const c10::DeviceGuard guard(idx.device());
     need(idx, "idx", at::kLong);
+    TORCH_CHECK(K > 0, "K must be positive");
     Tensor enc = at::empty({idx.numel(), K}, idx.options().dtype(at::kFloat));
     ok(t5vq_one_hot_f32(idx.data_ptr<int64_t>(), idx.numel(), K, enc.data_ptr<float>(), stream_of(idx)), "one_hot");
     return enc;

@@ -238,3 +238,30 @@ def test_self_contained_search_ties_and_eval_module():
     out = m(x)
     assert (out[3].view(-1)[:8] == 5).all()
     assert torch.equal(out[3], m.get_indices(x))
+
+
+def test_ops_reject_arguments_that_would_read_out_of_bounds():
+    """torch.ops.t5vq.* check sizes (and devices) before a pointer reaches a kernel: a short gradient, an index
+    tensor of the wrong length, shapes that disagree, a CPU tensor."""
+    from t5vqvae_amd import _lib
+    t = _lib.load_torch_ops()
+    dev = "cuda"
+    diff = torch.zeros(8, 64, device=dev)
+    one = torch.ones((), device=dev)
+    with pytest.raises(RuntimeError, match="element count"):
+        t.ste_backward(torch.zeros(4, 64, device=dev), diff, one, 1.0)
+    with pytest.raises(RuntimeError, match="scalar"):
+        t.ste_backward(None, diff, torch.ones(2, device=dev), 1.0)
+    with pytest.raises(RuntimeError, match="one code per row"):
+        t.scatter_rows(diff, torch.zeros(7, dtype=torch.int64, device=dev), None, 1.0, 16)
+    with pytest.raises(RuntimeError, match="same shape"):
+        t.cosine_backward(diff, torch.zeros(8, 32, device=dev), None, one, 1.0, 1.0, False)
+    with pytest.raises(RuntimeError, match="disagree on D"):
+        t.vq_forward(diff, torch.zeros(16, 32, device=dev), None, None, None, 0, False, False, False, False, False)
+    with pytest.raises(RuntimeError, match="row norms"):
+        t.vq_forward(diff, torch.zeros(16, 64, device=dev), None, torch.zeros(7, device=dev), None, 0, False, False,
+                     False, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path|ROCm device"):
+        t.code_sqnorms(torch.zeros(16, 64))
+    assert t.ste_backward(None, diff, one, 1.0).shape == diff.shape          # the valid forms still run
+    assert t.scatter_rows(diff, torch.zeros(8, dtype=torch.int64, device=dev), None, 1.0, 16).shape == (16, 64)
