@@ -195,9 +195,11 @@ def distances(x, w, xx=None, ee=None):
     if xx is None or ee is None:
         return _lib.load_torch_ops().distances(x, w)
     lib = _lib.load()
-    _need(x, "x", ndim=2), _need(w, "w", ndim=2)
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(xx, "xx", ndim=1), _need(ee, "ee", ndim=1)
     n, d = x.shape
     k = w.shape[0]
+    if w.shape[1] != d or xx.shape[0] != n or ee.shape[0] != padded_codes(k):
+        raise RuntimeError("distances: inconsistent shapes")
     out = torch.empty(n, k, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.t5vq_distances_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, _p(out), _stream(x)), "distances")
@@ -244,8 +246,12 @@ def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, 
     _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(keys, "keys", torch.int64, 1)
     n, d = x.shape
     k = w.shape[0]
+    if w.shape[1] != d or keys.numel() != n:
+        raise RuntimeError("gather_stats: x, w and keys disagree on N or D")
     if stats_count is None:
         stats_count = k - stats_begin
+    if stats_begin < 0 or stats_count < 0 or stats_begin + stats_count > k:
+        raise RuntimeError(f"gather_stats: statistics slice [{stats_begin}, {stats_begin + stats_count}) outside [0, {k})")
     for name, t, shape in (("ste", ste, (n, d)), ("q", q, (n, d)), ("diff", diff, (n, d)),
                            ("counts", counts, (stats_count,)), ("embed_sum", embed_sum, (stats_count, d)),
                            ("loss_partial", loss_partial, (n if perm is not None else gather_blocks(n),))):
@@ -255,6 +261,8 @@ def gather_stats(x, w, keys, loss: str = "mse", *, ste=None, q=None, diff=None, 
                 raise RuntimeError(f"{name}: expected {shape}, got {tuple(t.shape)}")
     if idx is not None:
         _need(idx, "idx", torch.int64)
+        if idx.numel() != n:
+            raise RuntimeError(f"idx: expected {n} elements")
     if perm is not None:
         _need(perm, "perm", torch.int32, 1)
         if perm.numel() != n:
