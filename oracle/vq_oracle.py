@@ -260,7 +260,9 @@ def blended_indices(state: VQState, source_code: torch.Tensor, target_code: torc
 def t5_layer_norm(hidden: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """T5LayerNorm.forward, python_transformers/modeling_t5.py:200-207 (fp32 branch): RMS norm without mean
     subtraction, learned scale.  PARITY UNPINNED against the reference: python_transformers does not import here
-    (ModuleNotFoundError: sacremoses), so this restatement is checked against the cited lines only."""
+    (ModuleNotFoundError: sacremoses), so this restatement is checked against the cited lines, against
+    the upstream `transformers` T5LayerNorm the fork was cut from (to a few ulp: upstream multiplies by rsqrt) and
+    against torch's dropout for the mask convention (tests/test_oracle_golden.py) -- not against the fork itself."""
     variance = hidden.to(torch.float32).pow(2).mean(-1, keepdim=True)       # :202
     x = hidden / torch.sqrt(variance + eps)                                 # :203
     return weight * x                                                       # :207

@@ -26,3 +26,27 @@ def test_oracle_matches_reference(name, path):
         else:
             err = gc.compare(got[key], exp[key])
             assert err <= TOL[path], (key, err)
+
+
+def test_encoder_tail_oracle_against_upstream_layer_norm_and_torch_dropout():
+    """The encoder tail has no fixture in the reference and its python_transformers fork does not
+    import here (ModuleNotFoundError: sacremoses), so oracle.t5_layer_norm stays 'parity unpinned' against the
+    reference itself.  Two independent checks narrow that: (a) the T5LayerNorm of the installed upstream
+    `transformers`, the library the fork was cut from -- upstream multiplies by rsqrt where the fork (and the
+    restatement, modeling_t5.py:203) divides by sqrt, so equal to a few ulp, not bitwise; (b) torch's own dropout for
+    the mask convention: with the mask torch drew, oracle.encoder_tail reproduces F.dropout bit for bit."""
+    from oracle import vq_oracle as vo
+    t5 = pytest.importorskip("transformers.models.t5.modeling_t5")
+    torch.manual_seed(3)
+    ln = t5.T5LayerNorm(768, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(768))
+    hidden = torch.randn(8, 45, 768) * 3.0
+    ours = vo.t5_layer_norm(hidden, ln.weight.detach(), 1e-6)
+    upstream = ln(hidden).detach()
+    assert float(((ours - upstream).abs() / upstream.abs().clamp_min(1e-30)).max()) <= 1e-6
+    dropped = torch.nn.functional.dropout(ours, 0.1, True)
+    keep = dropped != 0                      # no exact zeros among the normalised activations of this draw
+    assert int((ours == 0).sum()) == 0
+    assert torch.equal(vo.encoder_tail(hidden, ln.weight.detach(), 1e-6, keep, 0.1), dropped)
+    assert torch.equal(vo.encoder_tail(hidden, ln.weight.detach(), 1e-6, None), ours)
