@@ -130,11 +130,12 @@ def test_role_order_is_a_permutation_for_any_codebook_size(k, offset):
                          torch.full_like(lo, t * (t + 1)))
     assert bool((bucket[order.long()].diff() >= 0).all())
     if k <= 5000:
-        w = synth.normal((k, d), 31, 0, device="cuda")
-        x = synth.normal((n, d), 32, 0, device="cuda")
-        xx, ee = ops.row_sqnorms(x, w)
-        plain = ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset)
-        assert torch.equal(ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset, order=order), plain)
+        for dd in (d, 100):          # 100: not a multiple of the 32-float chunk -> the first-generation kernel, which
+            w = synth.normal((k, dd), 31, 0, device="cuda")     # takes the tokens in their own order whatever `order` says
+            x = synth.normal((n, dd), 32, 0, device="cuda")
+            xx, ee = ops.row_sqnorms(x, w)
+            plain = ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset)
+            assert torch.equal(ops.dist_argmin(x, w, xx, ee, rg, code_offset=offset, order=order), plain)
 
 
 def test_cosine_loss_vs_oracle():
