@@ -93,8 +93,20 @@ __device__ __forceinline__ float sq4(const f32x4 v, float s) {
 }
 __device__ __forceinline__ float row_sqnorm_wave(const float* __restrict__ row, int D, int lane) {
     const f32x4* p = reinterpret_cast<const f32x4*>(row);
+    const int n4 = D >> 2;
     float s = 0.f;
-    for (int i = lane; i < (D >> 2); i += 64) s = sq4(p[i], s);
+    // four loads in flight per lane (a 768-float row is three of them): pieces past the row's end are zeros, and adding
+    // 0 * 0 to a non-negative sum leaves its bits alone, so the chain is the plain one, float4 by float4 in order
+    for (int base = lane; base < n4; base += 256) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + 64 * j;
+            v[j] = i < n4 ? p[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = sq4(v[j], s);
+    }
     return wave_sum(s);
 }
 
@@ -990,27 +1002,72 @@ __global__ __launch_bounds__(256) void code_hist_kernel(const long long* __restr
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(work + K, s_groups);
 }
+// PER > 0: each thread owns PER consecutive counters, kept in registers between the two passes and moved as int4 where
+// the pointer allows (K = 8192: two loads and two stores per thread instead of sixteen dependent round trips).
+// PER == 0: any K, the counters are read twice.
+template <int PER>
 __global__ __launch_bounds__(1024) void code_scan_kernel(int* __restrict__ work, int N, int K) {  // in place: exclusive scan
     __shared__ int s_wave[16];
     __shared__ int s_used[16];
-    const int per = (K + 1023) / 1024;
+    const int per = PER > 0 ? PER : (K + 1023) / 1024;
     const int b = threadIdx.x * per;
     int local = 0, used = 0;
-    for (int i = 0; i < per; ++i)
-        if (b + i < K) {
-            const int c = work[b + i];
-            local += c;
-            used += c > 0;
+    int c[PER > 0 ? PER : 1];
+    const bool vec = PER >= 4 && (reinterpret_cast<uintptr_t>(work) & 15u) == 0;
+    if (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            if (PER >= 4 && vec && b + j + 3 < K) {
+                const int4 v = *reinterpret_cast<const int4*>(work + b + j);
+                c[j] = v.x;
+                if (PER >= 4) { c[j + 1 < PER ? j + 1 : 0] = v.y; c[j + 2 < PER ? j + 2 : 0] = v.z; c[j + 3 < PER ? j + 3 : 0] = v.w; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < PER) c[j + e] = b + j + e < K ? work[b + j + e] : 0;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            local += c[j];
+            used += c[j] > 0;
+        }
+    } else {
+        for (int i = 0; i < per; ++i)
+            if (b + i < K) {
+                const int v = work[b + i];
+                local += v;
+                used += v > 0;
+            }
+    }
     used = static_cast<int>(wave_sum(static_cast<float>(used)));   // <= 64 * per: exact in fp32
     if ((threadIdx.x & 63) == 0) s_used[threadIdx.x >> 6] = used;
     int run = block_exclusive_scan(local, s_wave);
-    for (int i = 0; i < per; ++i)
-        if (b + i < K) {
-            const int c = work[b + i];
-            work[b + i] = run;
-            run += c;
+    if (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            int o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = run;
+                if (j + e < PER) run += c[j + e];
+            }
+            if (PER >= 4 && vec && b + j + 3 < K) {
+                *reinterpret_cast<int4*>(work + b + j) = int4{o[0], o[1], o[2], o[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < PER && b + j + e < K) work[b + j + e] = o[e];
+            }
         }
+    } else {
+        for (int i = 0; i < per; ++i)
+            if (b + i < K) {
+                const int v = work[b + i];
+                work[b + i] = run;
+                run += v;
+            }
+    }
     if (threadIdx.x == 0) {
         int codes_used = 0;
         for (int i = 0; i < 16; ++i) codes_used += s_used[i];
@@ -2241,6 +2298,21 @@ int t5vq_gather_stats_f32(const float* x, const float* w, const int64_t* keys, i
 
 static int order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work, bool work_zeroed,
                          hipStream_t stream);
+// exclusive scan of work[0, K) by one workgroup; the counters-per-thread form that covers K
+static void launch_code_scan(int32_t* work, int64_t N, int64_t K, hipStream_t stream) {
+    const int64_t per = (K + 1023) / 1024;
+#define T5VQ_SCAN(PER_) \
+    hipLaunchKernelGGL(code_scan_kernel<PER_>, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), static_cast<int>(K))
+    if (per <= 1) { T5VQ_SCAN(1); }
+    else if (per <= 2) { T5VQ_SCAN(2); }
+    else if (per <= 4) { T5VQ_SCAN(4); }
+    else if (per <= 8) { T5VQ_SCAN(8); }
+    else if (per <= 16) { T5VQ_SCAN(16); }
+    else if (per <= 32) { T5VQ_SCAN(32); }
+    else if (per <= 64) { T5VQ_SCAN(64); }
+    else { T5VQ_SCAN(0); }
+#undef T5VQ_SCAN
+}
 int t5vq_order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* perm, int32_t* work,
                        t5vq_stream_t stream_) {
     return order_by_code(keys, N, K, perm, work, false, static_cast<hipStream_t>(stream_));
@@ -2254,7 +2326,7 @@ static int order_by_code(const int64_t* keys, int64_t N, int64_t K, int32_t* per
     if (!work_zeroed) T5VQ_CHECK_HIP(hipMemsetAsync(work, 0, static_cast<size_t>(K + 2) * 4, stream));
     const dim3 grid(static_cast<unsigned>((N + 255) / 256));
     hipLaunchKernelGGL(code_hist_kernel, grid, dim3(256), 0, stream, kp, static_cast<int>(N), static_cast<int>(K), work);
-    hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), static_cast<int>(K));
+    launch_code_scan(work, N, K, stream);
     hipLaunchKernelGGL(code_place_kernel, grid, dim3(256), 0, stream, kp, static_cast<int>(N), static_cast<int>(K), work,
                        perm);
     T5VQ_CHECK_HIP(hipGetLastError());
@@ -2286,7 +2358,7 @@ static int order_by_range(const int64_t* range, int64_t N, int64_t K, int64_t co
     const dim3 grid(static_cast<unsigned>((N + 255) / 256));
     const long long* rg = reinterpret_cast<const long long*>(range);
     hipLaunchKernelGGL(range_hist_kernel, grid, dim3(256), 0, stream, rg, static_cast<int>(N), rb, work);
-    hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, work, static_cast<int>(N), bins);
+    launch_code_scan(work, N, bins, stream);
     hipLaunchKernelGGL(range_place_kernel, grid, dim3(256), 0, stream, rg, static_cast<int>(N), rb, work, order);
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
