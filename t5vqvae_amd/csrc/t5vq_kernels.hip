@@ -1334,16 +1334,34 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
 // Sum of n loss terms in a FIXED order (four strided fp64 accumulators per thread, wave butterflies, wave totals in
 // wave order): the same value whichever kernel calls it.  1024 threads; the total is valid in thread 0.
 __device__ __forceinline__ double sum_terms_1024(const float* __restrict__ p, long long n, double* s /*[16]*/) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent loads in flight; fixed order for a given n
-    long long i = threadIdx.x;
-    for (; i + 3 * 1024 < n; i += 4 * 1024) {
-        const float v0 = p[i], v1 = p[i + 1024], v2 = p[i + 2048], v3 = p[i + 3072];
-        a0 += static_cast<double>(v0);
-        a1 += static_cast<double>(v1);
-        a2 += static_cast<double>(v2);
-        a3 += static_cast<double>(v3);
+    // Thread t owns the groups of four terms #t, #t + 1024, ...; accumulator e takes element e of each group.  The
+    // order depends on n alone: a 16-byte aligned pointer moves a group as one float4 (two in flight), any other
+    // pointer reads the same elements one by one into the same accumulators.
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const long long n4 = n >> 2;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(p);
+        long long g = threadIdx.x;
+        for (; g + 1024 < n4; g += 2048) {
+            const f32x4 u = q[g], v = q[g + 1024];
+            a0 += static_cast<double>(u.x); a1 += static_cast<double>(u.y);
+            a2 += static_cast<double>(u.z); a3 += static_cast<double>(u.w);
+            a0 += static_cast<double>(v.x); a1 += static_cast<double>(v.y);
+            a2 += static_cast<double>(v.z); a3 += static_cast<double>(v.w);
+        }
+        if (g < n4) {
+            const f32x4 u = q[g];
+            a0 += static_cast<double>(u.x); a1 += static_cast<double>(u.y);
+            a2 += static_cast<double>(u.z); a3 += static_cast<double>(u.w);
+        }
+    } else {
+        for (long long g = threadIdx.x; g < n4; g += 1024) {
+            a0 += static_cast<double>(p[4 * g]); a1 += static_cast<double>(p[4 * g + 1]);
+            a2 += static_cast<double>(p[4 * g + 2]); a3 += static_cast<double>(p[4 * g + 3]);
+        }
     }
-    for (; i < n; i += 1024) a0 += static_cast<double>(p[i]);
+    const long long tail = n4 << 2;   // the last n % 4 terms: threads 0..2, accumulator 0
+    if (tail + threadIdx.x < n) a0 += static_cast<double>(p[tail + threadIdx.x]);
     const double acc = wave_sum_d((a0 + a1) + (a2 + a3));
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
