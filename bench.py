@@ -335,6 +335,7 @@ def c5_shard_config(dev, search, iters, check):
 
 def single_gpu_configs(args, dev):
     """Every BASELINE configuration one GPU can hold besides the headline, plus the assignment regimes of c3."""
+    import torch
     out = []
     plan = [("c1", "uniform"), ("c2", "uniform"), ("c4", "uniform"), ("c3", "uniform"), ("c3", "cold"),
             ("c3", "collapsed")]
@@ -361,6 +362,18 @@ def single_gpu_configs(args, dev):
             leg = cpu_leg(k, d, update, args.search, state, dev, 2880 if wl == "c1" else 4096, 0.0, desc)
             entry["parity"] = leg["parity"]
             entry["cpu_ref_vectors_per_s_one_call"] = leg["value"]
+        # the module's default search ("auto") takes the other mode from N*K = 2^23 on: the same call, same protocol, with
+        # that mode, and whether it returns the headline mode's indices
+        other = "filter" if args.search == "scan" else "scan"
+        if d % 64 == 0 and n * k >= mod.filter_min_work:
+            mod.search = other
+            omed, omn, ores = per_call_ms(mod, x, w, ema_w, cs, args.config_iters)
+            entry["other_search"] = {"search": other, "ms_per_call_median": omed, "ms_per_call_min": omn,
+                                     "vectors_per_s": n / (omed * 1e-3),
+                                     "indices_identical_to_headline_mode": bool(torch.equal(ores[3], res[3]))}
+            if regime == "uniform":
+                entry["other_search"]["ms_back_to_back"] = back_to_back_ms(mod, x, w, ema_w, cs, 2 * args.config_iters)
+            mod.search = args.search
         out.append(entry)
         del mod, state, w, ema_w, cs, x
     out.append(c5_shard_config(dev, args.search, args.config_iters, not args.no_cpu_baseline))
@@ -444,23 +457,28 @@ def search_kernel_roofline(mod, x, n, k, d, args, workload):
     filt = args.search == "filter" or (args.search == "auto" and d % 64 == 0 and n * k >= mod.filter_min_work)
     search = (lambda: ops.dist_argmin_filtered(flat, wq, xx, ee, keys=keys, exact_keys=False)) if filt \
         else (lambda: ops.dist_argmin(flat, wq, xx, ee, keys=keys))
-    for _ in range(2):
+    for _ in range(3):
         search()
-    reps = 10
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    reps = 30
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:                     # one event pair per launch, all queued back to back, read after one sync
+        a.record()
         search()
-    e1.record()
+        b.record()
     torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / reps
+    per_launch = sorted(a.elapsed_time(b) for a, b in evs)
+    # the median launch: a single stall of the box (seen once: one launch of 14 ms among 5.7 ms ones) moves a mean of
+    # few launches by several per cent and says nothing about the kernel; mean, min and max are reported beside it
+    k_ms = statistics.median(per_launch)
     peak = PEAK_F16_MFMA_TFLOPS if filt else PEAK_FP32_MFMA_TFLOPS
     kname = "filtered search: filter_f16_kernel + prep/collect/refine" if filt \
         else "dist_mfma_v2_kernel (fused distance+argmin)"
     flops = 2.0 * n * k * d
     achieved = flops / (k_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "kernel_ms": k_ms, "flops_per_launch": flops,
+            "frac": achieved / peak, "kernel_ms": k_ms, "kernel_ms_stat": f"median of {reps} launches, HIP events per launch",
+            "kernel_ms_mean": sum(per_launch) / reps, "kernel_ms_min": per_launch[0], "kernel_ms_max": per_launch[-1],
+            "flops_per_launch": flops,
             "traffic": None if filt else measured_traffic(workload),
             "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
             "algorithmic_bytes": 4.0 * (n * d + k * d) + 12.0 * n + 4.0 * k}
