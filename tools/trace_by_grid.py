@@ -7,6 +7,7 @@ grid size the headline shape stands on its own row (C3: the fused distance + arg
     python3 tools/trace_by_grid.py <rocprofv3 output dir> > profiles/<tag>_kernels_by_grid.csv"""
 import csv
 import glob
+import re
 import sys
 from collections import defaultdict
 
@@ -14,10 +15,14 @@ rows = defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "anonymous namespace" not in name or "at::native" in name:
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)      # left mangled by the profiler (a _Float16 parameter)
+        if m:
+            short = name[m.end():m.end() + int(m.group(1))]
+        elif "anonymous namespace" not in name or "at::native" in name:
             continue
-        short = name.split("(anonymous namespace)::", 1)[-1]
-        short = short.split("(float", 1)[0].split("(long", 1)[0].split("(int", 1)[0].replace("(anonymous namespace)::", "")
+        else:
+            short = name.split("(anonymous namespace)::", 1)[-1]
+            short = short.split("(float", 1)[0].split("(long", 1)[0].split("(int", 1)[0].replace("(anonymous namespace)::", "")
         wg = int(r["Workgroup_Size_X"]) or 1
         rows[(short, int(r["Grid_Size_X"]) // wg, wg)].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 out = csv.writer(sys.stdout)
