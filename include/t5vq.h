@@ -303,7 +303,11 @@ int t5vq_vq_forward_f32(const float* x, const float* w, const int64_t* range, co
  * must not exceed T5VQ_NOALLOC_SCRATCH_BYTES -- e.g. N = 131072 with K = 16384, or N = 65536 with K = 65536;
  * larger shapes return T5VQ_ERR_INVALID with a message.  Every call on a GPU shares that GPU's array: calls that
  * overlap on one GPU (two streams, two host threads) race on it -- serialise them; calls on one stream are ordered
- * by the stream.  Nothing is carried from one call to the next (every temporary is rewritten before it is read). */
+ * by the stream.  Nothing is carried from one call to the next (every temporary is rewritten before it is read).
+ * Under HIP graph capture: make ONE call per device outside capture first (any shape of the kind to be captured) --
+ * the first call on a device looks up the scratch symbol (hipGetSymbolAddress) and sets the kernels' dynamic-LDS
+ * attribute (hipFuncSetAttribute), which a capture may refuse; every later call only enqueues kernels and is
+ * capturable (tests/test_zz_no_alloc.py captures, replays and compares). */
 #define T5VQ_NOALLOC_SCRATCH_BYTES (4 << 20)
 int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
                                 const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, float* out_ste,

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,7 +66,14 @@ TORCH_LIB_PATH = os.environ.get("T5VQ_TORCH_LIB") or os.path.join(_HERE, "csrc",
 
 _lib = None
 _torch_ops = None
+# A failed load is remembered and re-raised: a second ``dlopen`` / ``torch.ops.load_library`` of a library whose first
+# load threw half-way (its static registrations partly run) is undefined -- in round 2 such a retry, made by the autograd
+# worker thread of a backward-only flow, hung inside ``run_backward``.
+_lib_error = None
+_torch_ops_error = None
 
+
+_load_lock = threading.RLock()
 
 ABI_VERSION = 210     # t5vq_version() of the library these signatures were written against (the `order` arguments)
 
@@ -76,9 +84,25 @@ class T5VQError(RuntimeError):
 
 def load() -> ctypes.CDLL:
     """Load the HIP library (once).  Raises if it is missing -- there is no CPU path."""
-    global _lib
+    global _lib, _lib_error
     if _lib is not None:
         return _lib
+    if _lib_error is not None:
+        raise _lib_error
+    with _load_lock:
+        if _lib is not None:
+            return _lib
+        if _lib_error is not None:
+            raise _lib_error
+        try:
+            _lib = _load_c_abi()
+        except BaseException as e:      # sticky: never dlopen twice
+            _lib_error = e
+            raise
+    return _lib
+
+
+def _load_c_abi() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise T5VQError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -92,24 +116,41 @@ def load() -> ctypes.CDLL:
     if int(lib.t5vq_version()) < ABI_VERSION:
         raise T5VQError(f"{LIB_PATH} is version {int(lib.t5vq_version())}, this binding needs >= {ABI_VERSION}: "
                         "rebuild it (`make -C t5vqvae_amd/csrc all`)")
-    _lib = lib
     return lib
 
 
 def load_torch_ops():
     """``torch.ops.t5vq`` (once): the TORCH_LIBRARY extension csrc/t5vq_torch.cpp.  Raises if it is missing."""
-    global _torch_ops
+    global _torch_ops, _torch_ops_error
     if _torch_ops is not None:
         return _torch_ops
-    import torch
-    load()                                   # libt5vq.so first: the extension links against it
-    if not os.path.exists(TORCH_LIB_PATH):
-        raise T5VQError(
-            f"{TORCH_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C t5vqvae_amd/csrc`.  t5vqvae_amd has no CPU fallback.")
-    torch.ops.load_library(TORCH_LIB_PATH)
-    _torch_ops = torch.ops.t5vq
+    if _torch_ops_error is not None:
+        raise _torch_ops_error
+    with _load_lock:
+        if _torch_ops is not None:
+            return _torch_ops
+        if _torch_ops_error is not None:
+            raise _torch_ops_error
+        try:
+            import torch
+            load()                                   # libt5vq.so first: the extension links against it
+            if not os.path.exists(TORCH_LIB_PATH):
+                raise T5VQError(
+                    f"{TORCH_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C t5vqvae_amd/csrc`.  t5vqvae_amd has no CPU fallback.")
+            torch.ops.load_library(TORCH_LIB_PATH)
+            _torch_ops = torch.ops.t5vq
+        except BaseException as e:      # sticky: torch.ops.load_library is never retried on a half-registered library
+            _torch_ops_error = e
+            raise
     return _torch_ops
+
+
+def load_all():
+    """Load both libraries NOW, on the calling thread (the modules' constructors call this): no ``dlopen`` can then
+    happen later on another thread -- the first caller of a backward-only op is the autograd worker thread."""
+    load()
+    return load_torch_ops()
 
 
 def check(status: int, what: str):

@@ -2015,8 +2015,11 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + C::CODE_TILE - 1) / C::CODE_TILE;
     int64_t splits = 1;
+    // the restructured main loop (and with it the ranged form that divides each token tile's OWN code range among the
+    // splits) runs only for these shapes; the general kernel cuts the whole codebook statically
+    const bool v2 = V2 && !dist && !opts.bounded && !opts.tok_list && D % C::BKC == 0;
     if (!dist) {
-        splits = plan_splits(N, K, D, C::CODE_TILE, nullptr, range != nullptr && !opts.bounded && V2);
+        splits = plan_splits(N, K, D, C::CODE_TILE, nullptr, range != nullptr && v2);
         if (g_force_splits > 0) {
             splits = g_force_splits;
             while (splits > code_tiles) splits /= 2;
@@ -2038,7 +2041,6 @@ int launch_dist_cfg(const float* x, const float* w, const float* xx, const float
 #define T5VQ_DIST_ARGS                                                                                        \
     x, w, xx, ee, rg, static_cast<int>(N), static_cast<int>(K), static_cast<int>(D), static_cast<int>(splits), \
         static_cast<int>(tiles_per_split), static_cast<long long>(code_offset)
-    const bool v2 = V2 && !dist && !opts.bounded && !opts.tok_list && D % C::BKC == 0;
     const bool d2 = v2 && D % (2 * C::BKC) == 0 && g_depth2;
     if (v2 && range && d2) {
         hipLaunchKernelGGL((dist_mfma_v2_kernel<C, true, true>), grid, dim3(256), C::LDS_BYTES, stream,
@@ -2828,8 +2830,9 @@ int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* r
     void* ptr = nullptr;
     const int rc = scratch_for_current_device(&ptr);
     if (rc != T5VQ_OK) return rc;
-    // every temporary is (re)written before it is read: keys are filled with 'none' and the statistics zeroed by the
-    // first launch, the sort cursors by a memset on `stream`; nothing of the previous call's contents is used
+    // every temporary is (re)written before it is read: keys are filled with 'none', the statistics and the sort
+    // cursors zeroed by the preparation tail of the first launch (or by the self-contained kernel's workgroups); nothing
+    // of the previous call's contents is used
     return vq_forward_impl(x, w, range, xx_in, ee_in, N, K, D, loss_kind, ptr, out_ste, out_q, out_diff, idx_out,
                            counts, embed_sum, loss_terms, loss_sum, static_cast<hipStream_t>(stream_));
 }

@@ -55,12 +55,6 @@ struct StatsLayout {
     }
 };
 
-// 0-dim tensor over element i of `buf` that is NOT a view of it (callers do `loss += ...` on the result, which autograd
-// refuses on a view handed out by a custom Function), at no kernel's cost.
-inline Tensor scalar_of(const Tensor& buf, int64_t i) {
-    return at::empty({0}, buf.options()).set_(buf.storage(), buf.storage_offset() + i, {}, {});
-}
-
 struct Fwd {
     Tensor ste, idx, stats;
     OptTensor diff, q, unsettled;
@@ -163,8 +157,9 @@ Tensor vq_finalize(const OptTensor& cs, const OptTensor& ema_w, const OptTensor&
 }
 
 // vq_step = the whole module call on one GPU: vq_forward then vq_finalize, one dispatcher crossing.
-// Returns (ste, idx, diff?, q?, scalars, unsettled?, loss, perplexity) -- the last two 0-dim, over scalars[0..1].
-std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor, Tensor, Tensor> vq_step(
+// Returns (ste, idx, diff?, q?, scalars, unsettled?); loss / perplexity are scalars[0..1] -- the 0-dim tensors over them
+// are made by the Python caller (vqvae._scalar_of): outputs that alias each other would break the schema's promise.
+std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_step(
     const Tensor& x, const Tensor& w, const OptTensor& ranges, const OptTensor& xx, const OptTensor& ee,
     const OptTensor& cs, const OptTensor& ema_w, int64_t loss_kind, bool filtered, bool want_diff, bool want_q,
     double loss_denom, double decay, double one_minus_decay, double epsilon, double k_epsilon, double commitment_cost,
@@ -175,7 +170,7 @@ std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor, Tensor, Tens
     Tensor scalars = finalize_impl(cs, ema_w, wopt, r.stats, x.size(0), w.size(0), x.size(1), update, false, x.size(0),
                                    loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
                                    update, ee_out);
-    return {r.ste, r.idx, r.diff, r.q, scalars, r.unsettled, scalar_of(scalars, 0), scalar_of(scalars, 1)};
+    return {r.ste, r.idx, r.diff, r.q, scalars, r.unsettled};
 }
 
 // vq_backward (MSE): grad_x = g_out - diff * (g_loss * coef)   (t5vq_ste_backward_f32)
@@ -289,7 +284,7 @@ TORCH_LIBRARY(t5vq, m) {
     m.def("vq_step(Tensor x, Tensor(c!) w, Tensor? ranges, Tensor? xx, Tensor? ee, Tensor(a!)? cluster_size, "
           "Tensor(b!)? ema_w, int loss_kind, bool filtered, bool want_diff, bool want_q, float loss_denom, float decay, "
           "float one_minus_decay, float epsilon, float k_epsilon, float commitment_cost, bool plain_variant, bool update, "
-          "Tensor(d!)? ee_out) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?, Tensor, Tensor)");
+          "Tensor(d!)? ee_out) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
     m.def("ste_backward(Tensor? g_out, Tensor diff, Tensor? g_loss, float coef) -> Tensor");
     m.def("scatter_rows(Tensor rows, Tensor idx, Tensor? scale_dev, float scale_host, int K) -> Tensor");
     m.def("cosine_backward(Tensor x, Tensor q, Tensor? g_out, Tensor? g_loss, float coef_x, float coef_q, "

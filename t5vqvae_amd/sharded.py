@@ -26,12 +26,19 @@ Code sharding (BASELINE config 5) -- ``CodeShardedVectorQuantizerEMA``.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch import nn
 
 from . import vqvae
 from .vqvae import _QuantizerBase
+
+# The gathered codebook a code-sharded module keeps between calls: module -> (full [K, D], local data_ptr, local
+# _version, pending c10d work | None).  A weak side table, like vqvae._EE_STATE / _FILTER_STATE: a c10d Work and a K x D
+# tensor in the module's __dict__ would break copy.deepcopy / torch.save(module) or bloat them.
+_FULL_STATE = weakref.WeakKeyDictionary()
 
 
 def shard_tokens(module, group=None, world_tokens: int = 0):
@@ -86,7 +93,41 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         self.disentanglement = disentanglement
         self.loss = loss
         self.exchange = "prefetch"       # "prefetch" | "sync": when the gathered codebook is refreshed (module docstring)
-        self._full = None                # (gathered codebook [K, D], local data_ptr, local _version, pending work | None)
+
+    # --- the kept gathered codebook: when it is dropped --------------------------------------------------
+    # Keep-or-re-gather is a COLLECTIVE decision (a rank that re-gathers alone waits for the others forever), so it is
+    # taken from things that happen on every rank alike: this module's own EMA update (always refreshes), a switch
+    # between train() and eval(), a state-dict load, a move (.to / .cuda), and invalidate_code_norms(), which the
+    # caller must run on every rank after writing through ``_embedding.weight.data``.  A tracked in-place change of the
+    # local slice (copy_, an optimizer step) is seen through the Parameter's version as well; like any collective call
+    # it has to be made by every rank of the group.
+    def invalidate_code_norms(self):
+        """Drop the cached |e|^2 AND the kept gathered codebook.  Call it on EVERY rank of the group (the next forward
+        re-gathers collectively) after a write through ``_embedding.weight.data``, which no version counter sees."""
+        super().invalidate_code_norms()
+        _FULL_STATE.pop(self, None)
+
+    def __deepcopy__(self, memo):
+        """A copy shares the process group (a communicator is not copyable) and starts without a kept codebook."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for name, value in self.__dict__.items():
+            new.__dict__[name] = value if name == "group" else copy.deepcopy(value, memo)
+        return new
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            _FULL_STATE.pop(self, None)
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        _FULL_STATE.pop(self, None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        _FULL_STATE.pop(self, None)
+        return super()._load_from_state_dict(*args, **kwargs)
 
     # --- state in the reference's (unsharded) layout -------------------------------------------------
     @torch.no_grad()
@@ -96,6 +137,7 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         self._embedding.weight.copy_(full["_embedding.weight"][sl])
         self._ema_w.copy_(full["_ema_w"][sl])
         self._ema_cluster_size.copy_(full["_ema_cluster_size"][sl])
+        self.invalidate_code_norms()
 
     @torch.no_grad()
     def full_state_dict(self) -> dict:
@@ -114,28 +156,30 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         slice changes in the same calls); a refresh started by ``_refresh_full_codebook`` is waited for here, on the
         stream (no host wait)."""
         param = self._embedding.weight
-        ent = self._full
+        ent = _FULL_STATE.get(self)
         if (self.exchange == "prefetch" and ent is not None and ent[1] == param.data_ptr()
                 and ent[2] == param._version and ent[0].device == w_local.device):
             if ent[3] is not None:
                 ent[3].wait()                    # current stream waits for RCCL's stream
-                self._full = (ent[0], ent[1], ent[2], None)
+                _FULL_STATE[self] = (ent[0], ent[1], ent[2], None)
             return ent[0]
+        if ent is not None and ent[3] is not None:
+            ent[3].wait()                        # a refresh in flight writes the buffer that is gathered into below
         full = ent[0] if (ent is not None and ent[0].device == w_local.device) else \
             torch.empty(self._num_embeddings, self._embedding_dim, dtype=w_local.dtype, device=w_local.device)
         dist.all_gather_into_tensor(full, w_local.contiguous(), group=self.group)
-        self._full = (full, param.data_ptr(), param._version, None)
+        _FULL_STATE[self] = (full, param.data_ptr(), param._version, None)
         return full
 
     def _refresh_full_codebook(self):
         """After the EMA update of the local slice: start the all-gather of the new slices into the kept buffer
         (in place: the collective is ordered after this call's row gather, which was the buffer's last reader) and
         return at once; the next ``_full_codebook`` waits for it."""
-        ent = self._full
+        ent = _FULL_STATE.get(self)
         if self.exchange != "prefetch" or ent is None:
             return
         work = dist.all_gather_into_tensor(ent[0], self._embedding.weight.data, group=self.group, async_op=True)
-        self._full = (ent[0], ent[1], ent[2], work)
+        _FULL_STATE[self] = (ent[0], ent[1], ent[2], work)
 
     def _global_keys(self, x, w_local, ranges):
         keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin)
@@ -171,10 +215,10 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
         denom = float(n * d) if mse else float(plan.batch)
         cs = self._ema_cluster_size if update else None
-        args = (counts, partial, kl, n, denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, False)
-        ops.ema_cluster(cs, *args, 2, scalars)                                   # local partial sums
+        tail = (kl, n, denom, plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, False)
+        ops.ema_cluster(cs, counts, None, *tail, 2, scalars)                     # local partial sums (no loss yet)
         dist.all_reduce(scalars[1:3], op=dist.ReduceOp.SUM, group=self.group)    # entropy, sum(cluster_size)
-        ops.ema_cluster(cs, *args, 3, scalars)                                   # smoothing + perplexity
+        ops.ema_cluster(cs, counts, partial, *tail, 3, scalars)                  # smoothing + perplexity + loss
         if fixed:
             max_bits = ops.max_norm(ops.row_sqnorms(x, None)[0])                 # tokens are replicated: same scale
             esum = ops.embed_sum_fixed(x, idx, max_bits, k, stats_begin=self.code_begin, stats_count=kl)

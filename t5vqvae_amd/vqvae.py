@@ -23,7 +23,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from .roles import INDEX_MODES
 
 BUCKET_MIN_TOKENS = 1024     # ranged search: tokens are visited role by role from this many on (= the library's rule)
@@ -114,6 +114,12 @@ class _QuantizerBase(nn.Module):
     # of the plain variant) are scaled by the group size, so that the average equals the single-process gradient on
     # the concatenated batch.  "sum": the caller sums them (or all-reduces with SUM) -- no scaling.
     gradient_reduction = "mean"
+
+    def __init__(self):
+        super().__init__()
+        # both libraries are loaded here, on the constructing thread: the first caller of a backward-only op is the
+        # autograd worker thread, and a dlopen (or a failing one, retried) must never happen there
+        _lib.load_all()
 
     def _flatten(self, inputs, srl):
         flat = inputs.view(-1, self._embedding_dim)          # same view rule as vqvae/vqvae.py:103
@@ -291,14 +297,15 @@ class _QuantizerBase(nn.Module):
         dims = (n_total, d, k, batch)
 
         if not bucketed and not fixed and plan.group is None:        # the whole call behind one op
-            ste, idx, diff, q, scalars, ovf, loss, ppl = ops.fused_step(
+            ste, idx, diff, q, scalars, ovf = ops.fused_step(
                 x, w, ranges, plan.loss, xx=plan.xx, ee=ee, cluster_size=cs, ema_w=ema_w, filtered=use_filter,
                 want_diff=want_diff, want_q=want_q, loss_denom=denom, update=update, ee_out=ee if update else None,
                 **hyper)
             if ovf is not None:
                 self._note_unsettled(ovf, n)
             self._last_scalars = scalars
-            return {"loss": loss, "ppl": ppl, "ste": ste, "idx": idx, "diff": diff, "q": q, "dims": dims}
+            return {"loss": _scalar_of(scalars, 0), "ppl": _scalar_of(scalars, 1), "ste": ste, "idx": idx, "diff": diff,
+                    "q": q, "dims": dims}
 
         with_es = update and not fixed
         reduce_loss = plan.group is not None

@@ -218,7 +218,7 @@ def fused_step(x, w, ranges, loss, *, xx=None, ee=None, cluster_size=None, ema_w
     scalars = fused_finalize(cluster_size, ema_w, w if update else None, stats, x.shape[0], w.shape[0], x.shape[1],
                              update, False, x.shape[0], loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
                              commitment_cost, plain_variant, update, ee_out)
-    return ste, idx, diff, q, scalars, ovf, scalars[0].clone(), scalars[1].clone()
+    return ste, idx, diff, q, scalars, ovf
 
 
 def rmsnorm_sqnorms(hidden, gamma, keep, scale, eps, want_rms=True):

@@ -71,15 +71,65 @@ def test_torch_extension_loads_and_registers_every_op():
 
 def test_missing_library_fails_loudly(monkeypatch):
     from t5vqvae_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
+    # the loaders remember a failure (next test): every cache is patched, so that undo() restores this process's state
+    for name in ("_lib", "_lib_error", "_torch_ops", "_torch_ops_error"):
+        monkeypatch.setattr(_lib, name, None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libt5vq.so")
     with pytest.raises(_lib.T5VQError, match="no CPU fallback"):
         _lib.load()
     monkeypatch.undo()
-    monkeypatch.setattr(_lib, "_torch_ops", None)
+    for name in ("_torch_ops", "_torch_ops_error"):
+        monkeypatch.setattr(_lib, name, None)
     monkeypatch.setattr(_lib, "TORCH_LIB_PATH", "/nonexistent/libt5vq_torch.so")
     with pytest.raises(_lib.T5VQError, match="no CPU fallback"):
         _lib.load_torch_ops()
+
+
+def test_failed_library_load_is_sticky_and_prompt(tmp_path):
+    """A library that fails to LOAD (here: a file that is no shared object) is tried once: the second call re-raises the
+    first error at once instead of calling dlopen / torch.ops.load_library again on a half-registered library, and the
+    modules load both libraries when they are constructed -- never first on the autograd worker thread.  (Round 2: such
+    a retry, made by a backward-only flow's worker thread, hung inside run_backward.)  Own process: the failure is
+    meant to stay with the process that saw it."""
+    import subprocess
+    import sys
+    bad = tmp_path / "libt5vq_torch.so"
+    bad.write_bytes(b"not a shared object")
+    code = r"""
+import time, sys
+from unittest import mock
+import torch
+from t5vqvae_amd import _lib
+calls = []
+real = torch.ops.load_library
+def counting(path):
+    calls.append(path)
+    return real(path)
+with mock.patch.object(torch.ops, "load_library", counting):
+    errs = []
+    for _ in range(2):
+        t0 = time.time()
+        try:
+            _lib.load_torch_ops()
+            sys.exit("load_torch_ops() did not raise")
+        except Exception as e:
+            errs.append(e)
+        assert time.time() - t0 < 5.0, "not prompt"
+    assert errs[0] is errs[1], "the second call must re-raise the first error"
+    assert len(calls) == 1, f"load_library called {len(calls)} times"
+    # the modules load eagerly: construction fails here, on this thread, with the same error
+    from t5vqvae_amd import VectorQuantizerEMA
+    try:
+        VectorQuantizerEMA(16, 8, 0.25, decay=0.99)
+        sys.exit("constructor did not raise")
+    except Exception as e:
+        assert e is errs[0]
+    assert len(calls) == 1
+print("ok")
+"""
+    env = dict(os.environ, T5VQ_TORCH_LIB=str(bad), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_module_contract_matches_reference_signatures():

@@ -34,11 +34,11 @@ def test_fused_step_equals_ctypes_composites(n, k, d, search):
                  commitment_cost=0.25, plain_variant=False)
     w_a, e_a, c_a = w.clone(), ema_w.clone(), cs.clone()
     ee_a = ops.code_sqnorms(w_a)
-    ste, idx, diff, q, scalars, ovf, loss, ppl = ops.fused_step(x, w_a, None, "mse", ee=ee_a, cluster_size=c_a,
-                                                                ema_w=e_a, filtered=search == "filter", want_diff=True,
-                                                                update=True, ee_out=ee_a, **hyper)
+    ste, idx, diff, q, scalars, ovf = ops.fused_step(x, w_a, None, "mse", ee=ee_a, cluster_size=c_a, ema_w=e_a,
+                                                     filtered=search == "filter", want_diff=True, update=True,
+                                                     ee_out=ee_a, **hyper)
     assert q is None and (ovf is not None) == (search == "filter")
-    assert loss.dim() == 0 and torch.equal(loss, scalars[0]) and torch.equal(ppl, scalars[1])
+    assert scalars.shape == (4,)
     # ctypes route, caller-allocated everything, no norms given, loss reduced by its own launch
     w_b, e_b, c_b = w.clone(), ema_w.clone(), cs.clone()
     b = dict(ste=torch.empty_like(x), diff=torch.empty_like(x), idx=torch.empty(n, dtype=torch.int64, device=DEV),

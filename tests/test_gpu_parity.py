@@ -1,5 +1,6 @@
 """HIP path vs the CPU oracle on seeded inputs (sizes the oracle finishes in seconds), edge shapes, and
-size-independent properties at the BASELINE sizes.  Everything goes through the C ABI (ctypes)."""
+size-independent properties at the BASELINE sizes.  Module-level tests call the nn.Modules (one ``torch.ops.t5vq``
+op per call, csrc/t5vq_torch.cpp, over the C ABI); the tests that name ``ops.*`` bind the C ABI directly with ctypes."""
 import pytest
 import torch
 
@@ -212,8 +213,20 @@ def test_ordered_tokens_give_the_same_statistics(pattern, loss):
     assert torch.equal(ls_ord, ls_again)
 
 
-def test_full_size_c3_vs_oracle():
-    """BASELINE config 3 (N=65536, K=8192) in the 'uniform' regime, whole step against the oracle."""
+def oracle_slice_check(x, w, idx, ranges=None, rows=4096):
+    """Indices of the first ``rows`` tokens against the oracle's distances + argmin on that slice (the band rule)."""
+    xs, ws = x[:rows].float().cpu(), w.float().cpu()
+    rs = None if ranges is None else ranges[:rows].cpu()
+    ref = vo.select_codes(vo.distances(xs, ws), rs)
+    outside, inside = vo.classify_mismatches(xs, ws, idx[:rows].cpu(), ref, rs)
+    assert outside == 0, f"{outside} index mismatches outside the band ({inside} inside)"
+    return inside
+
+
+@pytest.mark.parametrize("search", ["scan", "filter"])
+def test_full_size_c3_vs_oracle(search):
+    """BASELINE config 3 (N=65536, K=8192) in the 'uniform' regime, whole step against the oracle -- once with the
+    fp32 scan (the benchmark's headline search), once with the filtered search (what search="auto" takes here)."""
     n, k, d = 65536, 8192, 768
     from t5vqvae_amd import VectorQuantizerEMA
     w = synth.normal((k, d), 21, 0)
@@ -224,10 +237,11 @@ def test_full_size_c3_vs_oracle():
         m._ema_w.copy_(w * cs.unsqueeze(1))
         m._ema_cluster_size.copy_(cs)
     m.encodings = "indices"
+    m.search = search
     st = vo.VQState(w.clone(), w * cs.unsqueeze(1), cs.clone())
     x, c = synth.clustered(n, w, 0.5, 22)
     inside = check_step(m, st, x.view(64, 1024, d))
-    print("C3 in-band mismatches:", inside)
+    print(f"C3 ({search}) in-band mismatches:", inside)
 
 
 def test_full_size_properties_c3():
@@ -275,6 +289,15 @@ def test_full_size_properties_c4_share():
     ref_counts = torch.bincount(c, minlength=k).float()
     assert torch.equal(counts, ref_counts) and float(counts.sum()) == n
     assert rel(es, w * ref_counts.unsqueeze(1)) <= 1e-6
+    # against the oracle, on a slice the CPU finishes in seconds: noisy tokens (no exact hits), both searches at full size
+    xn, _ = synth.clustered(n, w.cpu(), 0.5, 93)
+    xn = xn.cuda()
+    xxn, _ = ops.row_sqnorms(xn, None)
+    scan = ops.dist_argmin(xn, w, xxn, ee)
+    filt = ops.dist_argmin_filtered(xn, w, xx=xxn, ee=ee)
+    assert torch.equal(scan, filt)
+    inside = oracle_slice_check(xn, w, ops.unpack_keys(scan)[0])
+    print("C4 share in-band mismatches on the oracle slice:", inside)
 
 
 def test_rejects_unsupported_inputs():

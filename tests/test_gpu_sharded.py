@@ -70,6 +70,17 @@ def test_c5_full_size_shards_equal_unsharded():
             assert bool(((idx >= 0) & (idx < width)).all())        # slice-relative, inside the role's width
         else:
             assert bool(((idx >= 0) & (idx < k)).all())
+        # the filtered search at full size gives the same indices, and both agree with the oracle (distances + the
+        # reference's slice-relative argmin, vqvae/vqvae.py:110-122) on a slice the CPU finishes in seconds
+        order = ops.order_by_range(rg, k) if roles else None
+        filt = ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, order=order, exact_keys=False)
+        assert torch.equal(ops.unpack_keys(filt)[0], idx)
+        rows = 1024
+        xs, wc = x[:rows].cpu(), w.cpu()
+        rs = rg[:rows].cpu() if roles else None
+        ref = vo.select_codes(vo.distances(xs, wc), rs)
+        outside, inside = vo.classify_mismatches(xs, wc, idx[:rows].cpu(), ref, rs)
+        assert outside == 0, f"{roles and len(roles)} roles: {outside} mismatches outside the band ({inside} inside)"
 
 
 def test_stats_slice_and_two_phase_cluster_update():

@@ -219,6 +219,35 @@ def _code_sharded_worker(rank, world, port, q, roles, training, deterministic=Fa
     dist.destroy_process_group()
 
 
+def _code_sharded_data_write_worker(rank, world, port, q):
+    """The kept gathered codebook after a write the version counter cannot see (``weight.data``): stale rows until
+    ``invalidate_code_norms()`` (called on every rank), fresh ones after; and the module stays deep-copyable."""
+    import copy
+    _init(rank, world, port)
+    from t5vqvae_amd.sharded import CodeShardedVectorQuantizerEMA, _FULL_STATE
+    m = CodeShardedVectorQuantizerEMA(K, D, 0.25, decay=0.99)
+    w0, w1 = synth.normal((K, D), 1, 0), synth.normal((K, D), 7, 3)
+    m.load_full_state_dict({"_embedding.weight": w0, "_ema_w": w0.clone(), "_ema_cluster_size": torch.ones(K)})
+    m.eval()
+    x = synth.normal((4, N // 4, D), 2, 0)
+    errs = [rel(m(x)[1], vo.get_hidden(vo.VQState(w0), x))]
+    assert m in _FULL_STATE and "_full" not in m.__dict__
+    sl = slice(m.code_begin, m.code_begin + m.local_codes)
+    m._embedding.weight.data.copy_(w1[sl])          # invisible to the Parameter's version counter
+    m.invalidate_code_norms()                        # ... so the caller says so, on every rank
+    assert m not in _FULL_STATE
+    errs.append(rel(m(x)[1], vo.get_hidden(vo.VQState(w1), x)))
+    assert torch.equal(m.get_indices(x), vo.get_indices(vo.VQState(w1), x))
+    # train() / eval() switches drop the kept codebook as well (the same event on every rank)
+    m.train()
+    assert m not in _FULL_STATE
+    m.eval()
+    c = copy.deepcopy(m)                             # no c10d Work / K x D tensor hides in the module's __dict__
+    assert torch.equal(c._embedding.weight, m._embedding.weight)
+    q.put((rank, max(errs)))
+    dist.destroy_process_group()
+
+
 def _run(worker, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -255,6 +284,10 @@ def test_token_sharded_plain_variant_gradients_gloo(reduction):
                                             ([(0, 50), (50, 200), (120, 256), (3, 5)], True)])  # straddling
 def test_code_sharded_equals_single_process_gloo(roles, training):
     _run(_code_sharded_worker, roles, training)
+
+
+def test_code_sharded_kept_codebook_follows_data_writes_gloo():
+    _run(_code_sharded_data_write_worker)
 
 
 def test_code_sharded_deterministic_is_bit_identical_to_unsharded_gloo():

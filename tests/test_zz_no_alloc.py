@@ -57,12 +57,17 @@ def test_noalloc_forward_equals_workspace_forward_twice():
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     d = 768
-    # first call: enough tokens for the ordered statistics walk (every region of the scratch is used);
-    # second call: smaller N AND smaller K, the ranged search, no token ordering -- over the first call's leftovers
-    # third call: ranged AND ordered walk -- the token-order region holds the role order during the search and is
-    # rewritten with the by-code order for the statistics kernel
+    # 1: enough tokens for the ordered statistics walk (every region of the scratch is used);
+    # 2: smaller N AND smaller K, the ranged search with the tokens visited role by role (N >= 1024), no ordering by
+    #    code -- over the first call's leftovers;
+    # 3: ranged AND ordered walk -- the token-order region holds the role order during the search and is rewritten
+    #    with the by-code order for the statistics kernel;
+    # 4: ranged, fewer than 1024 tokens: no role order at all, over what case 3 left in that region;
+    # 5: a small plain problem (C2's shape): the single-launch small-shape forward and its own use of the scratch;
+    # 6: the same with statistics for a training step
     cases = [(40000, 1000, None), (1500, 300, [(0, 100), (100, 300), (20, 250)]),
-             (36000, 900, [(0, 300), (300, 900), (100, 500)])]
+             (36000, 900, [(0, 300), (300, 900), (100, 500)]), (700, 300, [(0, 100), (100, 300), (20, 250)]),
+             (4096, 512, None), (1000, 256, None)]
     for i, (n, k, roles) in enumerate(cases):
         x = synth.normal((n, d), 70 + i, 0).to(dev)
         w = synth.normal((k, d), 70 + i, 1).to(dev)
@@ -75,6 +80,38 @@ def test_noalloc_forward_equals_workspace_forward_twice():
     x = synth.normal((n, d), 70, 0).to(dev)
     w = synth.normal((k, d), 70, 1).to(dev)
     _compare(_run(lib, x, w, None, noalloc=True), _run(lib, x, w, None, noalloc=False))
+
+
+def test_noalloc_forward_is_capturable_after_a_warm_up_call():
+    """Inside HIP graph capture a hipMalloc (or any other forbidden call) fails the capture: after ONE warm-up call per
+    device outside capture (include/t5vq.h: the first call looks up the scratch symbol and sets kernel attributes) the
+    entry point is captured, replayed on new inputs, and equals the workspace form."""
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    d = 768
+    for n, k in ((3000, 1000), (4096, 512)):
+        x = synth.normal((n, d), 90, 0).to(dev)
+        w = synth.normal((k, d), 90, 1).to(dev)
+        _run(lib, x, w, None, noalloc=True)                      # the warm-up call, outside capture
+        o = _outputs(n, k, d, dev)
+        xs = torch.zeros_like(x)                                 # static input of the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                rc = lib.t5vq_vq_forward_noalloc_f32(_p(xs), _p(w), None, None, None, n, k, d, 0, _p(o["ste"]), None,
+                                                     _p(o["diff"]), _p(o["idx"]), _p(o["counts"]), _p(o["embed_sum"]),
+                                                     None, _p(o["loss_sum"]), stream)
+                _lib.check(rc, "noalloc under capture")
+        torch.cuda.current_stream().wait_stream(side)
+        for rep in range(2):                                     # replay twice, on different inputs
+            xr = synth.normal((n, d), 91 + rep, 0).to(dev)
+            xs.copy_(xr)
+            g.replay()
+            torch.cuda.synchronize()
+            _compare(o, _run(lib, xr, w, None, noalloc=False))
 
 
 def test_noalloc_forward_refuses_shapes_beyond_the_scratch():
