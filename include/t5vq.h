@@ -47,8 +47,9 @@ const char* t5vq_last_error(void);
 int t5vq_set_tuning(int variant);
 /* Length of the padded |e|^2 buffer for K codes: K rounded up to T5VQ_CODE_PAD. */
 int64_t t5vq_padded_codes(int64_t K);
-/* Number of per-workgroup loss partials t5vq_gather_stats_f32 writes for N tokens (a workgroup takes 64 tokens,
- * 16 when N < 32768 and 4 when N < 8192, so that small batches still cover the CUs). */
+/* Number of loss terms t5vq_gather_stats_f32 writes for N tokens when no token order (perm) is given: one per TOKEN
+ * when N < 32768 (the 4- and 16-token workgroups of small batches; the term then does not depend on how tokens are
+ * grouped), one per 64-token workgroup above. */
 int64_t t5vq_gather_blocks(int64_t N);
 
 /* Row squared norms of two matrices in one launch.
@@ -110,8 +111,9 @@ int t5vq_distances_f32(const float* x, const float* w, const float* xx, const fl
  *                    one flush per (workgroup, code) after an in-LDS segment sum)
  *                    both only for stats_begin <= k < stats_begin + stats_count (the whole codebook:
  *                    0, K; a code shard keeps statistics for its own slice only)
- *   loss_partial[b] = per-workgroup sum of (q-x)^2 (MSE) or of 1 - cos(q_i, x_i) (COSINE, ATen
- *                    cosine_embedding_loss form, eps 1e-12); length t5vq_gather_blocks(N) (nullable)
+ *   loss_partial[b] = sums of (q-x)^2 (MSE) or of 1 - cos(q_i, x_i) (COSINE, ATen cosine_embedding_loss form, eps
+ *                    1e-12), one per token (N < 32768) or one per 64-token workgroup; length t5vq_gather_blocks(N)
+ *                    (nullable)
  *   perm (nullable): the tokens in an order that puts equal codes next to each other (t5vq_order_by_code); a
  *                    workgroup then flushes one partial row per run of equal codes instead of one per token
  *                    Outputs stay in token order.  With perm, loss_partial holds one term per TOKEN (length N,
@@ -313,6 +315,31 @@ int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* r
                                 const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind, float* out_ste,
                                 float* out_q, float* out_diff, int64_t* idx_out, float* counts, float* embed_sum,
                                 float* loss_terms, float* loss_sum, t5vq_stream_t stream);
+
+/* The forward for SMALL problems in ONE launch (vqvae/vqvae.py:103-128,147-152,160, the statistics of :133,:141 and,
+ * with `scalars`, the loss / perplexity of :148,:157,:161-162 of a call WITHOUT an EMA update -- evaluation, or the plain
+ * variant): distance + argmin on fp32 MFMA, the code splits of a token tile merged inside the launch, gather /
+ * straight-through / loss terms / counts / embed_sum by the workgroup that merged them, the scalars by the workgroup that
+ * finishes last.  Results are those of t5vq_vq_forward_f32 (+ t5vq_vq_ema_finalize_f32 with update = 0) bit for bit
+ * (embed_sum up to the order of its atomic adds).  Shapes: t5vq_vq_forward_small_supported(N, K, D) -- fewer than 256
+ * tiles of 128 x 128, N < T5VQ_SMALL_MAX_TOKENS, D % 256 == 0, D <= 1024; plain search, mse loss.
+ * workspace: t5vq_forward_workspace_bytes(N, K) bytes, as for t5vq_vq_forward_f32.
+ * state: t5vq_small_state_bytes(K) bytes of device memory that the caller ZEROES ONCE (hipMemset) and then hands,
+ *   untouched, to every call (tickets of the hand-offs and the call's counts; each launch leaves it zeroed again, so no
+ *   call pays a memset).  Calls that share a state block must not overlap in time (one stream, or otherwise ordered).
+ * xx_in, ee_in (nullable) as in t5vq_vq_forward_f32 (a missing ee_in costs a row-norm launch over w).
+ * counts, embed_sum (nullable): zeroed by the call (a memset each), then accumulated.  loss_terms (nullable): N floats,
+ *   one term per token.  scalars (nullable, needs K % 4 == 0 and no embed_sum): [loss, perplexity, 0, raw latent loss]
+ *   as t5vq_ema_cluster_f32 mode 0 writes them from loss_denom / commitment_cost / plain_variant; counts (if given)
+ *   then receives a copy of the call's counts and costs no memset. */
+#define T5VQ_SMALL_MAX_TOKENS 32768
+int64_t t5vq_small_state_bytes(int64_t K);
+int t5vq_vq_forward_small_supported(int64_t N, int64_t K, int64_t D);
+int t5vq_vq_forward_small_f32(const float* x, const float* w, const float* xx_in, const float* ee_in, int64_t N,
+                              int64_t K, int64_t D, void* workspace, int64_t workspace_bytes, void* state,
+                              float* out_ste, float* out_q, float* out_diff, int64_t* idx_out, float* counts,
+                              float* embed_sum, float* loss_terms, float* scalars, float loss_denom,
+                              float commitment_cost, int plain_variant, t5vq_stream_t stream);
 
 /* The same forward (vqvae/vqvae.py:103-128,147-152,160 + :133,:141) with the filtered search of
  * t5vq_dist_argmin_filtered_f32 in place of the scan: identical indices and outputs, one host call.  Needs

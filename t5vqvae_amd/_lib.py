@@ -55,6 +55,10 @@ SIGNATURES = {
     "t5vq_forward_loss_terms": (I64, [I64, c_int]),
     "t5vq_vq_forward_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P]),
     "t5vq_vq_forward_noalloc_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, P, P, P, P, P, P, P, P]),
+    "t5vq_small_state_bytes": (I64, [I64]),
+    "t5vq_vq_forward_small_supported": (c_int, [I64, I64, I64]),
+    "t5vq_vq_forward_small_f32": (c_int, [P, P, P, P, I64, I64, I64, P, I64, P, P, P, P, P, P, P, P, P, c_float, c_float,
+                                          c_int, P]),
     "t5vq_forward_filtered_workspace_bytes": (I64, [I64, I64, I64]),
     "t5vq_vq_forward_filtered_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P,
                                              P]),
@@ -75,7 +79,7 @@ _torch_ops_error = None
 
 _load_lock = threading.RLock()
 
-ABI_VERSION = 210     # t5vq_version() of the library these signatures were written against (the `order` arguments)
+ABI_VERSION = 300     # t5vq_version() of the library these signatures were written against (the small-shape forward)
 
 
 class T5VQError(RuntimeError):

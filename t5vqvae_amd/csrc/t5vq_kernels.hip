@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
     __syncthreads();
     const int n_groups = s_ngroups;
 
+    const bool per_token = perm || TOK < GS_TOK;   // one loss term per token (else one per workgroup)
     float lsum = 0.f;  // MSE: sum (q-x)^2 over this lane's columns; COSINE: lane 0 holds sum of 1 - cos
     float* trow = tbuf + wave * (NCH * 256);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1271,8 +1272,10 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
             }
             float pd = 0.f, px = 0.f;
             // ordered tokens: which tokens share a workgroup varies from run to run, so the loss is kept per TOKEN
-            // and summed in token order afterwards -- the loss stays bit-reproducible
-            float acc = perm ? 0.f : lsum;
+            // and summed in token order afterwards -- the loss stays bit-reproducible.  Small batches (the 4- and
+            // 16-token forms) keep it per token too: the term then does not depend on how tokens are grouped, and the
+            // single-launch small-shape forward (t5vq_small.hip) produces the same terms
+            float acc = per_token ? 0.f : lsum;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c4 = j * 64 + lane;
@@ -1298,12 +1301,12 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
                 px = wave_sum(px);
                 const float den = sqrtf((qq + 1e-12f) * (px + 1e-12f));
                 const float term = 1.0f - pd / den;
-                if (perm) {
+                if (per_token) {
                     if (lane == 0 && loss_partial) loss_partial[s_tok[t]] = term;
                 } else if (lane == 0) {
                     lsum += term;
                 }
-            } else if (perm) {
+            } else if (per_token) {
                 acc = wave_sum(acc);
                 if (lane == 0 && loss_partial) loss_partial[s_tok[t]] = acc;
             } else {
@@ -1323,7 +1326,7 @@ __global__ __launch_bounds__(256) void gather_stats_kernel(
             }
         }
     }
-    if (loss_partial && !perm) {
+    if (loss_partial && !per_token) {
         lsum = wave_sum(lsum);
         if (lane == 0) s_red[wave] = lsum;
         __syncthreads();
@@ -2180,7 +2183,7 @@ int launch_dist_self(const float* x, const float* w, const float* xx, const floa
 // ================================================================================================
 extern "C" {
 
-int t5vq_version(void) { return 210; }
+int t5vq_version(void) { return 300; }
 int t5vq_set_tuning(int variant) {
     g_depth2 = variant >= 100000 ? 0 : 1;   // +100000: single staging register set
     variant %= 100000;
@@ -2190,7 +2193,9 @@ int t5vq_set_tuning(int variant) {
 }
 const char* t5vq_last_error(void) { return g_err; }
 int64_t t5vq_padded_codes(int64_t K) { return (K + T5VQ_CODE_PAD - 1) / T5VQ_CODE_PAD * T5VQ_CODE_PAD; }
-int64_t t5vq_gather_blocks(int64_t N) { const int64_t t = gs_tok(N); return (N + t - 1) / t; }
+// loss terms of the plain (unordered) statistics walk: one per token below GS_SMALL_N tokens, one per 64-token workgroup above
+int64_t t5vq_gather_blocks(int64_t N) { return N < GS_SMALL_N ? N : (N + GS_TOK - 1) / GS_TOK; }
+static int64_t gather_grid(int64_t N) { const int64_t t = gs_tok(N); return (N + t - 1) / t; }
 
 static int launch_row_sqnorms(const float* x, int64_t N, float* xx, const float* w, int64_t K, float* ee, int64_t D,
                               PrepArgs prep, hipStream_t stream) {
@@ -2271,7 +2276,7 @@ static int launch_gather(const float* x, const float* w, const int64_t* keys, in
         if (embed_sum && stats_count)
             T5VQ_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(stats_count) * D * 4, stream));
     }
-    const dim3 grid(static_cast<unsigned>(t5vq_gather_blocks(N)));
+    const dim3 grid(static_cast<unsigned>(gather_grid(N)));
     const size_t lds = static_cast<size_t>(4) * nch * 256 * 4;
     const long long* kp = reinterpret_cast<const long long*>(keys);
     long long* ip = reinterpret_cast<long long*>(idx_out);
@@ -2694,7 +2699,7 @@ int64_t t5vq_forward_workspace_bytes(int64_t N, int64_t K) {
 // training with N >= 32768) -> [gather + statistics] -> [loss sum].
 int64_t t5vq_forward_loss_terms(int64_t N, int with_embed_sum) {
     if (N <= 0) return 0;
-    return (with_embed_sum && N >= GS_SMALL_N) ? N : t5vq_gather_blocks(N);
+    return with_embed_sum ? N : t5vq_gather_blocks(N);   // ordered walk (N >= GS_SMALL_N) or small batch: one per token
 }
 
 static int vq_forward_impl(const float* x, const float* w, const int64_t* range, const float* xx_in,

@@ -353,6 +353,47 @@ def vq_forward_filtered(x, w, ranges, loss: str, *, xx=None, ee=None, ste=None, 
     return ovf
 
 
+def small_state(k: int, device) -> torch.Tensor:
+    """A zeroed state block for ``vq_forward_small`` (tickets + the call's counts); every call leaves it zeroed again."""
+    return torch.zeros(int(_lib.load().t5vq_small_state_bytes(k)), dtype=torch.uint8, device=device)
+
+
+def small_supported(n: int, k: int, d: int) -> bool:
+    return bool(_lib.load().t5vq_vq_forward_small_supported(n, k, d))
+
+
+def vq_forward_small(x, w, state, *, xx=None, ee=None, ste=None, q=None, diff=None, idx=None, counts=None,
+                     embed_sum=None, loss_terms=None, scalars=None, loss_denom: float = 1.0,
+                     commitment_cost: float = 0.0, plain_variant: bool = False):
+    """The single-launch forward for small problems (t5vq_vq_forward_small_f32, ctypes route).  ``state``: a block from
+    ``small_state`` that only calls ordered after one another share.  With ``scalars`` ([4]) the launch also writes
+    loss / perplexity (a call without an EMA update)."""
+    lib = _lib.load()
+    _need(x, "x", ndim=2), _need(w, "w", ndim=2), _need(state, "state", torch.uint8)
+    n, d = x.shape
+    k = w.shape[0]
+    if w.shape[1] != d:
+        raise RuntimeError("vq_forward_small: x and w disagree on D")
+    if state.numel() < int(lib.t5vq_small_state_bytes(k)):
+        raise RuntimeError("state block smaller than t5vq_small_state_bytes(K)")
+    for name, t, numel in (("xx", xx, n), ("ee", ee, padded_codes(k)), ("ste", ste, n * d), ("q", q, n * d),
+                           ("diff", diff, n * d), ("counts", counts, k), ("embed_sum", embed_sum, k * d),
+                           ("loss_terms", loss_terms, n), ("scalars", scalars, 4)):
+        if t is not None:
+            _need(t, name)
+            if t.numel() != numel:
+                raise RuntimeError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
+    if idx is not None and (_need(idx, "idx", torch.int64).numel() != n):
+        raise RuntimeError(f"idx: expected {n} elements")
+    nbytes = forward_workspace_bytes(n, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.t5vq_vq_forward_small_f32(_p(x), _p(w), _p(xx), _p(ee), n, k, d, _p(ws), nbytes, _p(state), _p(ste),
+                                                 _p(q), _p(diff), _p(idx), _p(counts), _p(embed_sum), _p(loss_terms),
+                                                 _p(scalars), loss_denom, commitment_cost, 1 if plain_variant else 0,
+                                                 _stream(x)), "vq_forward_small")
+
+
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: int, loss_denom: float, decay: float,
                  one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float,
                  plain_variant: bool, update: bool, scalars, ee_out=None):

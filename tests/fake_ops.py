@@ -20,7 +20,7 @@ def padded_codes(k):
 
 
 def gather_blocks(n):
-    return (n + 63) // 64
+    return n if n < 32768 else (n + 63) // 64
 
 
 def row_sqnorms(x, w):
@@ -122,7 +122,7 @@ def gather_stats(x, w, keys, loss="mse", *, ste=None, q=None, diff=None, idx=Non
             per = (df * df).sum(1)
         else:
             per = 1 - (qq * x).sum(1) / (((qq * qq).sum(1) + 1e-12) * ((x * x).sum(1) + 1e-12)).sqrt()
-        if perm is not None:
+        if perm is not None or n < 32768:
             loss_partial.copy_(per)
         else:
             pad = torch.zeros(gather_blocks(n) * 64)
@@ -138,7 +138,7 @@ def order_by_code(keys, k):
 
 
 def forward_loss_terms(n, with_embed_sum):
-    return n if (with_embed_sum and n >= ORDER_MIN_TOKENS) else gather_blocks(n)
+    return n if with_embed_sum else gather_blocks(n)
 
 
 def vq_forward(x, w, ranges, loss, *, xx=None, ee=None, ste=None, q=None, diff=None, idx=None, counts=None,

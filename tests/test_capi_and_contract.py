@@ -27,8 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
     assert lib.t5vq_version() >= 100
     assert lib.t5vq_padded_codes(10000) == 10112 and lib.t5vq_padded_codes(128) == 128
-    assert lib.t5vq_gather_blocks(65) == 17 and lib.t5vq_gather_blocks(10000) == 625 \
-        and lib.t5vq_gather_blocks(65536) == 1024                                    # 4 / 16 / 64 tokens per workgroup
+    assert lib.t5vq_gather_blocks(65) == 65 and lib.t5vq_gather_blocks(10000) == 10000 \
+        and lib.t5vq_gather_blocks(65536) == 1024                 # one loss term per token / per 64-token workgroup
 
 
 def test_invalid_arguments_are_rejected_before_any_launch():

@@ -63,7 +63,7 @@ def test_loss_terms_summed_by_the_finalize_kernel():
         w, ema_w, cs = _state(k, d, 5)
         x, _ = synth.clustered(n, w, 0.7, 6)
         n_terms = ops.forward_loss_terms(n, with_es)
-        assert n_terms == (n if (with_es and n >= 32768) else ops.gather_blocks(n))
+        assert n_terms == (n if with_es else ops.gather_blocks(n))
         terms = torch.empty(n_terms, device=DEV)
         loss_sum = torch.empty(1, device=DEV)
         counts = torch.empty(k, device=DEV)
