@@ -7,25 +7,30 @@
 //   * a workgroup owns 32 tokens against a slice of the codebook (all of it when the grid is large enough without a
 //     split); each of its four waves takes the 32 tokens x its own 32 NT codes on v_mfma_f32_32x32x2_f32, operands in
 //     the distance kernel's layout and k order, so every dot product is the same fma chain, bit for bit;
-//   * every wave stages ITS OWN operand rows (global -> registers, PD chunks ahead -> its private double-buffered LDS
-//     image): LDS operations of one wave execute in order, so the main loop has NO workgroup barrier at all -- the
-//     distance kernel's 128 x 64 form pays one per 32-deep chunk with a single wave per SIMD to cover it (58 % of peak
-//     at C2).  The price: the 32 x 32 token block of a chunk is fetched by all four waves (L1 hits after the first);
-//   * |x|^2 is accumulated from the staged rows in row_sqnorm_wave's lane layout and order (bit-identical to
-//     t5vq_row_sqnorms_f32), the epilogue is the distance kernel's: d = fl(fl(xx + ee) - 2 dot), first minimum wins;
-//   * the S workgroups that share a token tile (code splits) hand their 32 packed keys to the one that finishes last:
-//     sc1 (write-through) stores, s_waitcnt vmcnt(0), one agent-scope ticket add -- the workgroup whose add returns
-//     S - 1 reads the S x 32 keys back with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms,
-//     row 1: no fence, no polling, nobody waits);
-//   * that workgroup gathers its 32 codewords, writes the straight-through output fl(x + fl(q - x)), q - x, the
-//     indices, one loss term per token, and adds its counts (one atomic per (workgroup, code): the tokens are grouped
-//     in LDS first) and, in training, its rows to embed_sum;
-//   * with `scalars` the launch also ends the call: the workgroup that finishes its gather last (a second ticket)
-//     reads every count (agent-scope acquire: they were written by atomics) and every loss term (sc1) and writes
-//     loss / perplexity in ema_cluster_kernel's own summation orders (bit-identical to t5vq_ema_cluster_f32 mode 0).
+//   * every wave stages ITS OWN operand rows by LDS-DMA (global_load_lds_dwordx4, two chunks ahead, a ring of three
+//     private stages): a wave reads only what it fetched itself, so its own vmcnt wait is all the ordering the main loop
+//     needs -- NO workgroup barrier, no VGPR round trip, no ds_write.  The price: the 32 x 32 token block of a chunk is
+//     fetched by all four waves (L1 hits after the first);
+//   * |x|^2 is summed from the token rows themselves, row_sqnorm_wave's way (bit-identical to t5vq_row_sqnorms_f32),
+//     the epilogue is the distance kernel's: d = fl(fl(xx + ee) - 2 dot), first minimum wins;
+//   * the S workgroups that share a token tile (code splits) hand their 32 packed keys over inside the launch: sc1
+//     (write-through) stores, s_waitcnt vmcnt(0), one agent-scope ticket add; whoever finishes last reads the keys back
+//     with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms, row 1: no fence).  Two splits that
+//     meet within a bounded poll share the gather, 16 tokens each; nobody waits without a bound;
+//   * the finishing workgroup(s) gather the codewords, write the straight-through output fl(x + fl(q - x)), q - x, the
+//     indices, one loss term per token, and add their counts (one atomic per (workgroup, code): the tokens are grouped
+//     in LDS first) and, in training, their rows to embed_sum;
+//   * with `scalars` the launch also ends the call: loss terms and codes leave first (sc1) and are signalled on a second
+//     ticket before the bulk stores; the workgroup whose signal completes the batch builds the histogram in LDS and
+//     writes loss / perplexity in ema_cluster_kernel's own summation orders (bit-identical to t5vq_ema_cluster_f32
+//     mode 0) -- no counts in global memory, no acquire.
 //
-// Tickets and (with `scalars`) the counts live in a small STATE block that the caller zeroes once; every launch
-// leaves it zeroed again (the last arrivers reset what they used), so no call pays a memset.
+// The tickets live in a small STATE block that the caller zeroes once; every launch leaves it zeroed again (whoever
+// touches a ticket last resets it), so no call pays a memset.
+//
+// Measured at C2 (tools/experiments/small_stamps.py, back to back): prologue 1.9 us, main loop 27.5 us (the same loop
+// with no staging at all: 23.0 us = 49152 MFMA cycles at the 2.14 GHz the chip holds here), epilogue + merge 2.2,
+// hand-off 1.9, gather 3.7-5, scalars 3-4: 45.0 us per call against 45.7 us for the three-launch chain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -39,13 +44,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef T5VQ_SMALL_ABL   // timing-only ablations of the main loop (diagnostic builds; results are wrong with any bit set
-#define T5VQ_SMALL_ABL 0 // but 8): 1 no global loads, 2 no ds_writes, 4 no fragment reads, 8 loads spread over all groups
+#ifndef T5VQ_SMALL_ABL   // timing-only ablations of the main loop (diagnostic builds; results are wrong unless 0):
+#define T5VQ_SMALL_ABL 0 // 1 no DMA in the loop, 2 every chunk fetches the same columns, 4 token rows not fetched
 #endif
 
 namespace {
-
-constexpr long long KEY_NONE = 0x7FFFFFFFFFFFFFFFLL;
 
 __device__ __forceinline__ long long pack_key(float d, int idx) {
     int b = __float_as_int(d);
@@ -76,12 +79,12 @@ typedef unsigned long long __attribute__((address_space(1))) gu64;
 typedef unsigned int __attribute__((address_space(1))) gu32;
 #define T5VQ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-#define T5VQ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-constexpr int SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+// s_waitcnt that waits for vmcnt <= n only (expcnt 7, lgkmcnt 15): vmcnt's low four bits sit in [3:0], the high two in [15:14]
+constexpr int vmcnt_only(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 
 constexpr int SM_TOK = 32;   // tokens per workgroup
 constexpr int SM_BKC = 32;   // floats of D per stage
-constexpr int SM_ROW = 36;   // LDS row stride in floats: 144 B = 9 x 16 B (conflict-free ds_read_b128, as in the scan)
 constexpr int SM_MAX_TILES = T5VQ_SMALL_MAX_TOKENS / SM_TOK;
 
 struct SmallArgs {
@@ -98,12 +101,11 @@ struct SmallArgs {
     float* out_q;
     float* out_diff;
     long long* idx_out;
-    float* counts;       // nullable; zero on entry (the caller's buffer, or the state block's when scalars are fused)
-    int reset_counts;    // with scalars: the last workgroup leaves `counts` zeroed again (the state block's invariant)
+    float* counts;       // nullable; without scalars: zero on entry, added to; with scalars: written by the last workgroup
     float* embed_sum;    // nullable; zero on entry
     float* loss_terms;   // [N], nullable
     float* scalars;      // nullable: [loss, perplexity, 0, raw latent loss] written by the last workgroup
-    float* counts_out;   // nullable (only with scalars): the counts copied out before the state block is re-zeroed
+    int* codes;          // [N] (only with scalars): every token's code, handed to the workgroup that finishes last
     float n_tokens, loss_denom, cc;
     int plain_variant;
     long long* stamps;   // diagnostic builds (-DT5VQ_SMALL_STAMPS): [workgroup][8] wall-clock stamps (100 MHz)
@@ -120,35 +122,55 @@ long long* g_stamps = nullptr;
 
 template <int NT, int PD>
 struct SmallCfg {
-    static_assert(PD == 2 || PD == 4, "register sets / prefetch distance");
     static constexpr int WROWS = 32 * NT;                       // codes per wave per code tile
     static constexpr int CODE_TILE = 4 * WROWS;                 // codes per workgroup per code tile
-    static constexpr int STAGE = (SM_TOK + WROWS) * SM_ROW;     // floats per wave per stage
-    static constexpr int WAVE_LDS = 2 * STAGE;                  // double buffer
+    static constexpr int STAGE = (SM_TOK + WROWS) * SM_BKC;     // floats per wave per stage: unpadded 128-byte rows
+    static constexpr int WAVE_LDS = 3 * STAGE;                  // ring of three stages: multiplied, landed / landing, being filled
     static constexpr int SHARED_OFF = 4 * WAVE_LDS;             // floats: start of the workgroup-shared tail
     // tail: xx [32] | keys [4][32] int64 | codes [32] int | group masks [32] u64 | group codes [32] int | misc [8] int
     static constexpr int LDS_BYTES = SHARED_OFF * 4 + 32 * 4 + 128 * 8 + 32 * 4 + 32 * 8 + 32 * 4 + 8 * 4 + 16 * 8;
 };
 
+// 16-byte sc1 loads of words handed over inside the launch (the write-through stores of other workgroups): four in
+// flight per thread, one wait.  The wait statement takes the registers as operands, so no use can be scheduled before it.
+__device__ __forceinline__ void load4_sc1(const float* p0, const float* p1, const float* p2, const float* p3, bool k0,
+                                          bool k1, bool k2, bool k3, f32x4 (&u)[4]) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    u[0] = u[1] = u[2] = u[3] = z;
+    if (k0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[0]) : "v"(p0) : "memory");
+    if (k1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[1]) : "v"(p1) : "memory");
+    if (k2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[2]) : "v"(p2) : "memory");
+    if (k3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[3]) : "v"(p3) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : : "memory");
+}
+
 // Sum of n loss terms in sum_terms_1024's order (t5vq_kernels.hip), by 256 threads that each play 4 of its 1024:
 // virtual thread v = threadIdx.x + 256 m has its real thread's lane and sits in virtual wave (threadIdx.x >> 6) + 4 m,
-// so a virtual wave's butterfly is a real wave's.  Loads are sc1 (the terms were handed over inside the launch).
+// so a virtual wave's butterfly is a real wave's.  Virtual thread v owns the groups of four terms v, v + 1024, ...;
+// accumulator e takes element e of each group (a group that does not exist adds +0: exact).
 __device__ __forceinline__ double sum_terms_as_1024(const float* p, long long n, double* s /*[16]*/) {
-    const gu32* g = (const gu32*)p;
     const long long n4 = n >> 2, tail = n4 << 2;
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0},
+           a3[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long long q0 = threadIdx.x; q0 < n4; q0 += 1024) {   // uniform trip count up to the last partial round
+        f32x4 u[4];
+        load4_sc1(p + 4 * q0, p + 4 * (q0 + 256), p + 4 * (q0 + 512), p + 4 * (q0 + 768), true, q0 + 256 < n4,
+                  q0 + 512 < n4, q0 + 768 < n4, u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a0[m] += static_cast<double>(u[m].x);
+            a1[m] += static_cast<double>(u[m].y);
+            a2[m] += static_cast<double>(u[m].z);
+            a3[m] += static_cast<double>(u[m].w);
+        }
+    }
     double acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const long long v = threadIdx.x + 256 * m;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (long long q = v; q < n4; q += 1024) {
-            a0 += static_cast<double>(__uint_as_float(__hip_atomic_load(g + 4 * q, T5VQ_RLX_AGENT)));
-            a1 += static_cast<double>(__uint_as_float(__hip_atomic_load(g + 4 * q + 1, T5VQ_RLX_AGENT)));
-            a2 += static_cast<double>(__uint_as_float(__hip_atomic_load(g + 4 * q + 2, T5VQ_RLX_AGENT)));
-            a3 += static_cast<double>(__uint_as_float(__hip_atomic_load(g + 4 * q + 3, T5VQ_RLX_AGENT)));
-        }
-        if (tail + v < n) a0 += static_cast<double>(__uint_as_float(__hip_atomic_load(g + tail + v, T5VQ_RLX_AGENT)));
-        acc[m] = wave_sum_d((a0 + a1) + (a2 + a3));
+        if (tail + v < n)
+            a0[m] += static_cast<double>(__uint_as_float(__hip_atomic_load((const gu32*)p + tail + v, T5VQ_RLX_AGENT)));
+        acc[m] = wave_sum_d((a0[m] + a1[m]) + (a2[m] + a3[m]));
     }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
@@ -164,18 +186,18 @@ __device__ __forceinline__ double sum_terms_as_1024(const float* p, long long n,
 
 // sum_k p_k log(p_k + 1e-10), p = counts / n_tokens, in ema_cluster_kernel<VEC>'s order (K % 4 == 0): thread t of 1024
 // owns the float4 groups t, t + 1024, ...; wave butterflies; the 16 wave totals in wave order.  Every thread returns it.
-__device__ __forceinline__ double entropy_as_1024(const float* counts, int K, float n_tokens, double* s /*[16]*/) {
-    const gu32* g = (const gu32*)counts;
+// The counts are the integers of an LDS histogram (exact in fp32, as the atomically added float counts are).
+__device__ __forceinline__ double entropy_as_1024(const int* hist, int K, float n_tokens, double* s /*[16]*/) {
+    const int k4n = K >> 2;
     double acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         double ent = 0.0;
-        for (int k4 = threadIdx.x + 256 * m; k4 < (K >> 2); k4 += 1024) {
+        for (int k4 = threadIdx.x + 256 * m; k4 < k4n; k4 += 1024) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float c = __uint_as_float(__hip_atomic_load(g + 4 * k4 + e, T5VQ_RLX_AGENT));
-                const float p = __fdiv_rn(c, n_tokens);
-                ent += static_cast<double>(__fmul_rn(p, logf(__fadd_rn(p, 1e-10f))));
+                const float pr = __fdiv_rn(static_cast<float>(hist[4 * k4 + e]), n_tokens);
+                ent += static_cast<double>(__fmul_rn(pr, logf(__fadd_rn(pr, 1e-10f))));
             }
         }
         acc[m] = wave_sum_d(ent);
@@ -195,18 +217,18 @@ template <int NT, int PD, int NCH>
 __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
     using C = SmallCfg<NT, PD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int WROWS = C::WROWS, CODE_TILE = C::CODE_TILE, STAGE = C::STAGE, ROW = SM_ROW;
+    constexpr int WROWS = C::WROWS, CODE_TILE = C::CODE_TILE, STAGE = C::STAGE;
     constexpr int NWV = 4 * NT;   // float4 of W per lane per stage (4 of X)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS stage addresses stay in SGPRs (M0)
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const int r8 = lane >> 3;   // staging: row r8 + 8 j, 16-byte piece c8
     const int c8 = lane & 7;
 
-    float* wl = lds + wave * C::WAVE_LDS;   // this wave's two stages
+    float* wl = lds + wave * C::WAVE_LDS;   // this wave's ring of stages
     float* s_xx = lds + C::SHARED_OFF;                                      // [32]
     long long* s_keys = reinterpret_cast<long long*>(s_xx + 32);            // [4][32]
     int* s_code = reinterpret_cast<int*>(s_keys + 128);                     // [32]
@@ -231,21 +253,20 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
     const int n_tiles = tile_end - tile_begin;   // >= 1: the host plans no empty split
     const int n_chunks = D / SM_BKC;             // a multiple of 8 (D % 256 == 0), >= PD
 
-    typedef const f32x4 __attribute__((address_space(1))) * gvec_t;
     typedef const float __attribute__((address_space(1))) * gptr_t;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const gptr_t xg = (gptr_t)a.x;
     const gptr_t wg = (gptr_t)a.w;
-    // staged X rows are taken in an order rotated by the wave id, so that slot 0 is row r8 + 8 wave: the rows whose
-    // |x|^2 THIS wave accumulates (a literal register index whatever the wave)
+    // LDS-DMA staging (global_load_lds_dwordx4): lane L of a wave-instruction fills the 16 bytes at base + 16 L = row
+    // L / 8, slot L % 8 of an 8-row slab of unpadded 128-byte rows; slot s of row r holds piece s ^ ((r >> 1) & 7) of the
+    // row's eight 16-byte pieces -- the bank swizzle sits on the SOURCE address.  No VGPR round trip, no ds_write: the
+    // register form of this loop spent its issue slots on 12 ds_write_b128 per chunk (13 cycles each on the store path).
     gptr_t xp[4];
-    int x_st[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = r8 + 8 * ((j + wave) & 3);
-        int t = tok_base + row;
+        int t = tok_base + 8 * j + r8;
         if (t > N - 1) t = N - 1;
-        xp[j] = xg + static_cast<size_t>(t) * D + 4 * c8;
-        x_st[j] = row * ROW + 4 * c8;
+        xp[j] = xg + static_cast<size_t>(t) * D + 4 * (c8 ^ (((r8 >> 1) + 4 * j) & 7));
     }
     gptr_t wpc[NWV], wpn[NWV];
     auto set_wptrs = [&](gptr_t (&wp)[NWV], int ct) {
@@ -253,160 +274,133 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
         for (int j = 0; j < NWV; ++j) {
             int c = (tile_begin + ct) * CODE_TILE + wave * WROWS + r8 + 8 * j;
             if (c > K - 1) c = K - 1;
-            wp[j] = wg + static_cast<size_t>(c) * D + 4 * c8;
+            wp[j] = wg + static_cast<size_t>(c) * D + 4 * (c8 ^ (((r8 >> 1) + 4 * j) & 7));   // row 32 + 8 j + r8
         }
     };
-    const int w_st = SM_TOK * ROW + r8 * ROW + 4 * c8;   // + 8 ROW j
-
     const int tok = tok_base + l31;
     float xv = a.xx ? a.xx[tok < N ? tok : N - 1] : 0.f;
-    float xacc[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) xacc[m] = 0.f;
-    // ring of |x|^2 accumulators: place 0 takes the chunk being staged, then the ring turns by one place, so that chunk
-    // kc always meets accumulator kc % 8 (row_sqnorm_wave's lane 8 (kc % 8) + c8) and 8 | n_chunks brings it home
-    auto acc_turn = [&](const f32x4 v) {
-        const float t0 = sq4(v, xacc[0]);
-#pragma unroll
-        for (int m = 0; m < 7; ++m) xacc[m] = xacc[m + 1];
-        xacc[7] = t0;
-    };
-
-    f32x4 sx[PD][4];
-    f32x4 sw[PD][NWV];
     set_wptrs(wpc, 0);
-    // prologue: chunks 0 .. PD-1 of tile 0 on their way, chunk 0 into stage 0
-#pragma unroll
-    for (int p = 0; p < PD; ++p) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sx[p][j] = *(gvec_t)(xp[j] + p * SM_BKC);
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) sw[p][j] = *(gvec_t)(wpc[j] + p * SM_BKC);
-    }
-    {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wl + x_st[j]) = sx[0][j];
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) *reinterpret_cast<f32x4*>(wl + w_st + 8 * ROW * j) = sw[0][j];
-        acc_turn(sx[0][0]);
-    }
+    float* st0 = wl;                 // stage of the chunk being multiplied
+    float* st1 = wl + STAGE;         // the next chunk's
+    float* st2 = wl + 2 * STAGE;     // the one being filled
 
-    const int rd_x = l31 * ROW + 4 * h;
-    const int rd_w = SM_TOK * ROW + l31 * ROW + 4 * h;
+    const int fl = (l31 >> 1) & 7;   // the reader's rows are 32 k + l31: (row >> 1) & 7 is the lane's
+    int roff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) roff[g] = l31 * SM_BKC + 4 * ((2 * g + h) ^ fl);
     struct Frag {
         f32x4 b;
         f32x4 a[NT];
     };
     Frag f[2];
     auto read_frag = [&](Frag& fr, const float* base, int g) {
-        fr.b = *reinterpret_cast<const f32x4*>(base + rd_x + 8 * g);
+        fr.b = *reinterpret_cast<const f32x4*>(base + roff[g]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) fr.a[t] = *reinterpret_cast<const f32x4*>(base + rd_w + t * 32 * ROW + 8 * g);
+        for (int t = 0; t < NT; ++t)
+            fr.a[t] = *reinterpret_cast<const f32x4*>(base + (SM_TOK + 32 * t) * SM_BKC + roff[g]);
     };
-    read_frag(f[0], wl, 0);   // same wave wrote it: LDS operations of one wave execute in order
-#ifdef T5VQ_SMALL_STAMPS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    T5VQ_STAMP(1);
-#endif
+    constexpr int NDMA = 4 + NWV;   // DMA wave-instructions per chunk
 
-    int buf = 0;
     f32x16 acc[NT];
     float best = __int_as_float(0x7F800000);
     int best_code = (tile_begin * CODE_TILE + wave * WROWS);
 
-    using NoAcc = std::integral_constant<int, 0>;
-    using DoAcc = std::integral_constant<int, 1>;
-    // One chunk: MFMAs on stage `buf`; global loads of the chunk PD ahead (pointers wp, column koff) into register set P;
-    // the next chunk (set P + 1) written to the other stage; first fragments of the next chunk read.
-    auto body = [&](const gptr_t (&wp)[NWV], int koff, auto parity, auto accm) {
-        constexpr int P = decltype(parity)::value;
-        constexpr int PN = (P + 1) % PD;
-        constexpr bool AM = decltype(accm)::value != 0;
-        const float* cur = wl + buf * STAGE;
-        float* nxt = wl + (buf ^ 1) * STAGE;
-        // set P's old contents (this chunk) went to LDS one chunk ago
-#if !(T5VQ_SMALL_ABL & 1)
+    // One chunk: the DMAs of the chunk two ahead (pointers wp, column koff) go to the idle stage; MFMAs on st0; before
+    // the last k-group, wait until only this body's DMAs are in flight (the next chunk has landed) and read its first
+    // fragments.
+    // The issue order below is the program order: every step ends in sched_barrier(0), which nothing may cross (left to
+    // itself hipcc clumps the twelve DMAs and the fragment reads in front of the chunk's MFMAs; sched_group_barrier
+    // pipelines were not honoured around the M0 writes of the DMAs).
+#define T5VQ_SB() __builtin_amdgcn_sched_barrier(0)
+    // The DMA is an asm statement: hipcc's wait-count pass counts a global_load_lds builtin on the LDS counter as well and
+    // then waits lgkmcnt(0) -- for the fragment reads just issued too -- in front of every MFMA group.  The statement's
+    // VMEM operation is therefore unknown to that pass: every wait for DMA data below is written by hand (vmcnt counts
+    // in order, so the compiler's own waits for ITS loads only become stricter by the extra operations in flight).
+    auto issue_one = [&](float* stage, const gptr_t (&wp)[NWV], int koff, int q) {
+        const gptr_t src = q < 4 ? xp[q] + koff : wp[q - 4] + koff;
+        const unsigned dst = static_cast<unsigned>(reinterpret_cast<size_t>(
+            (lds_ptr_t)(stage + (q < 4 ? 8 * q : SM_TOK + 8 * (q - 4)) * SM_BKC)));
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");   // (M0 is reserved: nothing else in this kernel uses it)
+    };
+    // prologue: chunks 0 and 1 of the first tile on their way; chunk 0 landed (a wave reads only what it fetched itself:
+    // its own vmcnt wait orders the DMA's LDS writes before its ds_reads), its first fragments read
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sx[P][j] = *(gvec_t)(xp[j] + koff);
+    for (int q = 0; q < NDMA; ++q) issue_one(st0, wpc, 0, q);
 #pragma unroll
-        for (int j = 0; j < NWV; ++j) sw[P][j] = *(gvec_t)(wp[j] + koff);
+    for (int q = 0; q < NDMA; ++q) issue_one(st1, wpc, SM_BKC, q);
+    // |x|^2 of this wave's 8 token rows, row_sqnorm_wave's way (lane l takes float4 #l, #l + 64, ...): requested now,
+    // right behind the first two chunks, summed after the first code tile -- bit-identical to t5vq_row_sqnorms_f32
+    f32x4 xr[8][NCH];
+    if (!a.xx) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int t = tok_base + 8 * wave + i;
+            if (t > N - 1) t = N - 1;
+            const f32x4* row = reinterpret_cast<const f32x4*>(a.x + static_cast<size_t>(t) * D);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) xr[i][j] = row[j * 64 + lane];
+        }
+        T5VQ_SB();
+        __builtin_amdgcn_s_waitcnt(vmcnt_only(NDMA + 8 * NCH));   // chunk 0 landed; chunk 1 and the rows may be in flight
+    } else {
+        __builtin_amdgcn_s_waitcnt(vmcnt_only(NDMA));
+    }
+    T5VQ_SB();
+    read_frag(f[0], st0, 0);
+#ifdef T5VQ_SMALL_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T5VQ_STAMP(1);
 #endif
+    auto body = [&](const gptr_t (&wp)[NWV], int koff, auto fetch_t) {
+        constexpr bool fetch = decltype(fetch_t)::value;
+        constexpr int M = 4 * NT;                                    // MFMAs per k-group
+        static_assert(NDMA + 1 <= 3 * M, "one DMA behind each MFMA from the chunk's second on, all before the last group");
+        read_frag(f[1], st0, 1);
+        T5VQ_SB();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#if !(T5VQ_SMALL_ABL & 4)
-            if (g < 3) read_frag(f[(g + 1) & 1], cur, g + 1);
-#else
-            if (g < 3) f[(g + 1) & 1] = f[g & 1];
-#endif
-            if (g == 2) {
-#if !(T5VQ_SMALL_ABL & 2)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(nxt + x_st[j]) = sx[PN][j];
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int j = 0; j < NWV; ++j) *reinterpret_cast<f32x4*>(nxt + w_st + 8 * ROW * j) = sw[PN][j];
-#else
-#pragma unroll
-                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(sx[PN][j]));
-#pragma unroll
-                for (int j = 0; j < NWV; ++j) asm volatile("" ::"v"(sw[PN][j]));
-#endif
-                if constexpr (AM) acc_turn(sx[PN][0]);
-            }
-#if !(T5VQ_SMALL_ABL & 4)
-            if (g == 3) read_frag(f[0], nxt, 0);
-#else
-            if (g == 3) f[0] = f[1];
-#endif
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[g & 1].a[t][j], f[g & 1].b[j], acc[t], 0, 0, 0);
-        }
-        // ---- issue order: per k-group 4 NT MFMAs; loads behind the MFMAs of groups 0-1, ds_writes behind group 2's,
-        //      fragment reads one per MFMA at the head of each group
-        constexpr int M = 4 * NT, R = NT + 1, NLD = 4 + NWV;
-#if T5VQ_SMALL_ABL == 0 || T5VQ_SMALL_ABL == 8
-#if T5VQ_SMALL_ABL == 8
-        // loads spread evenly over the four groups
-        constexpr int LG = (NLD + 3) / 4, Q = (NLD + M - 1) / M;
-        static_assert(LG <= M, "one load per MFMA at most");
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            T5VQ_SGB(SG_DS_RD, R);
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                T5VQ_SGB(SG_MFMA, 1);
-                if (i % 2 == 1 && i / 2 < (NLD - LG * g < LG ? NLD - LG * g : LG)) T5VQ_SGB(SG_VMEM_RD, 1);
-                if (g == 2) T5VQ_SGB(SG_DS_WR, Q);
+                    const int m = j * NT + t;                        // position inside the group
+                    const int q = g * M + m - 1;                      // DMA q goes behind the chunk's MFMA q + 1
+#if T5VQ_SMALL_ABL == 0
+                    if (fetch && q >= 0 && q < NDMA) issue_one(st2, wp, koff, q);
+#elif T5VQ_SMALL_ABL == 2   // timing only: every chunk fetches the same columns (L1 / L2 hits, same issue and LDS traffic)
+                    if (fetch && q >= 0 && q < NDMA) issue_one(st2, wp, 0, q);
+#elif T5VQ_SMALL_ABL == 4   // timing only: the token rows are not fetched
+                    if (fetch && q >= 4 && q < NDMA) issue_one(st2, wp, koff, q);
+#endif
+                    if (g == 3 && m == M / 2 - 1) {
+                        // the next chunk has landed once only this body's DMAs are in flight (a wave reads only what it
+                        // fetched itself: its own vmcnt wait orders the DMA's LDS writes before its ds_reads);
+                        // s_waitcnt vmcnt(n) alone: expcnt 7, lgkmcnt 15
+                        T5VQ_SB();
+#if T5VQ_SMALL_ABL == 0 || T5VQ_SMALL_ABL == 2
+                        __builtin_amdgcn_s_waitcnt(vmcnt_only(fetch ? NDMA : 0));
+#elif T5VQ_SMALL_ABL == 4
+                        __builtin_amdgcn_s_waitcnt(vmcnt_only(fetch ? NDMA - 4 : 0));
+#else
+                        __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+#endif
+                        T5VQ_SB();
+                        read_frag(f[0], st1, 0);
+                    }
+                    T5VQ_SB();
+                }
+            }
+            // the fragment set this group used is free once its MFMAs are issued: the group after next reads into it
+            if (g < 2) {
+                read_frag(f[g & 1], st0, g + 2);
+                T5VQ_SB();
             }
         }
-#else
-        constexpr int L0 = (NLD + 1) / 2, L1 = NLD - L0, Q = (NLD + M - 1) / M;
-        static_assert(L0 <= M && L1 <= M, "one load per MFMA at most");
-        T5VQ_SGB(SG_DS_RD, R);            // group 0: fragments of group 1, half of the loads
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            T5VQ_SGB(SG_MFMA, 1);
-            if (i < L0) T5VQ_SGB(SG_VMEM_RD, 1);
-        }
-        T5VQ_SGB(SG_DS_RD, R);            // group 1: fragments of group 2, the other half
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            T5VQ_SGB(SG_MFMA, 1);
-            if (i < L1) T5VQ_SGB(SG_VMEM_RD, 1);
-        }
-        T5VQ_SGB(SG_DS_RD, R);            // group 2: fragments of group 3, the ds_writes spread over its MFMAs
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            T5VQ_SGB(SG_MFMA, 1);
-            T5VQ_SGB(SG_DS_WR, Q);
-        }
-        T5VQ_SGB(SG_DS_RD, R);            // group 3: first fragments of the next chunk
-        T5VQ_SGB(SG_MFMA, M);
-#endif
-#endif
-        buf ^= 1;
+        float* t0 = st0;
+        st0 = st1;
+        st1 = st2;
+        st2 = t0;
     };
 
     // |e|^2 of this lane's codes in the tile, fetched at the top of the tile (the epilogue used to wait for them)
@@ -424,50 +418,37 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
     };
 
     for (int ct = 0; ct < n_tiles; ++ct) {
-        set_wptrs(wpn, ct + 1 < n_tiles ? ct + 1 : ct);
+        const bool more = ct + 1 < n_tiles;
+        set_wptrs(wpn, more ? ct + 1 : ct);
         f32x4 e4[NT][4];
         load_ee(e4, ct);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        // chunks 0 .. n_chunks - PD - 1 stage a chunk of this tile; the last PD ones stage chunks 0 .. PD - 1 of the next
-        // tile (a harmless reload on the last tile); the tile's very last body writes chunk 0 of the NEXT pass over the
-        // token rows to LDS, which must not reach the |x|^2 accumulators
-        for (int kc = 0; kc + PD < n_chunks; kc += PD) {
-            if constexpr (PD == 2) {
-                body(wpc, (kc + 2) * SM_BKC, std::integral_constant<int, 0>(), DoAcc());
-                body(wpc, (kc + 3) * SM_BKC, std::integral_constant<int, 1>(), DoAcc());
-            } else {
-                body(wpc, (kc + 4) * SM_BKC, std::integral_constant<int, 0>(), DoAcc());
-                body(wpc, (kc + 5) * SM_BKC, std::integral_constant<int, 1>(), DoAcc());
-                body(wpc, (kc + 6) * SM_BKC, std::integral_constant<int, 2>(), DoAcc());
-                body(wpc, (kc + 7) * SM_BKC, std::integral_constant<int, 3>(), DoAcc());
-            }
-        }
-        if constexpr (PD == 2) {
-            body(wpn, 0, std::integral_constant<int, 0>(), DoAcc());
-            body(wpn, SM_BKC, std::integral_constant<int, 1>(), NoAcc());
+        // chunks 0 .. n_chunks - 3 fetch a chunk of this tile; the last two fetch chunks 0 and 1 of the next tile, or
+        // nothing on the last tile
+        for (int kc = 0; kc + 2 < n_chunks; ++kc) body(wpc, (kc + 2) * SM_BKC, std::true_type());
+        if (more) {
+            body(wpn, 0, std::true_type());
+            body(wpn, SM_BKC, std::true_type());
         } else {
-            body(wpn, 0, std::integral_constant<int, 0>(), DoAcc());
-            body(wpn, SM_BKC, std::integral_constant<int, 1>(), DoAcc());
-            body(wpn, 2 * SM_BKC, std::integral_constant<int, 2>(), DoAcc());
-            body(wpn, 3 * SM_BKC, std::integral_constant<int, 3>(), NoAcc());
+            body(wpn, 0, std::false_type());
+            body(wpn, SM_BKC, std::false_type());
         }
 #pragma unroll
         for (int j = 0; j < NWV; ++j) wpc[j] = wpn[j];
         if (ct == n_tiles - 1) T5VQ_STAMP(2);
 
         if (ct == 0 && !a.xx) {
-            // wave_sum's xor butterfly: lane bits 5..3 = the 8 accumulators (ring at home), bits 2..0 = the 8 lanes of a row
-            const float n0 = xacc[0] + xacc[4], n1 = xacc[1] + xacc[5];
-            const float n2 = xacc[2] + xacc[6], n3 = xacc[3] + xacc[7];
-            const float p0 = n0 + n2, p1 = n1 + n3;
-            float q = p0 + p1;
-            q += __shfl_xor(q, 4);
-            q += __shfl_xor(q, 2);
-            q += __shfl_xor(q, 1);
-            if (c8 == 0) s_xx[r8 + 8 * wave] = q;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) sacc = sq4(xr[i][j], sacc);
+                sacc = wave_sum(sacc);
+                if (lane == 0) s_xx[8 * wave + i] = sacc;
+            }
             __syncthreads();
             xv = s_xx[l31];
         }
@@ -480,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int code = code0 + t * 32 + 8 * g4 + c;
-                    const float s = xv + e4[t][g4][c];
-                    const float d = fmaf(-2.0f, acc[t][g4 * 4 + c], s);
+                    const float sxe = xv + e4[t][g4][c];
+                    const float d = fmaf(-2.0f, acc[t][g4 * 4 + c], sxe);
                     if (d < best) {
                         best = d;
                         best_code = code;
@@ -508,19 +489,50 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
             key = o < key ? o : key;
         }
     }
+    // tokens of the tile (positions g_lo .. g_lo + g_cnt - 1) this workgroup finishes: all 32, or -- two code splits that
+    // meet within a bounded wait -- its own half
+    int g_lo = 0, g_cnt = SM_TOK;
     if (S > 1) {
         if (mine)
             __hip_atomic_store((gu64*)(a.slots + static_cast<size_t>(split) * N + my_tok),
                                static_cast<unsigned long long>(key), T5VQ_RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains before it signals
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add((gu32*)(a.tile_ticket + tile), 1u, T5VQ_RLX_AGENT);
-            const int last = old == static_cast<unsigned>(S - 1);
-            if (last) __hip_atomic_store((gu32*)(a.tile_ticket + tile), 0u, T5VQ_RLX_AGENT);   // reset for the next launch
-            s_misc[0] = last;
+            gu32* ticket = (gu32*)(a.tile_ticket + tile);
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, T5VQ_RLX_AGENT);
+            int role;   // 0 leave, 1 finish the whole tile, 2 finish my half
+            if (S == 2) {
+                // Two splits share the gather when they meet.  The first to arrive polls the ticket a bounded number of
+                // times; if its partner shows up it takes its half, else it marks the ticket (+16) and leaves, and the
+                // partner, seeing the mark, finishes the whole tile.  Whoever touches the word last resets it.  No
+                // workgroup waits for another without a bound, so nothing depends on both being resident at once.
+                if (old == 0) {
+                    unsigned v = 1;
+                    for (int spins = 0; spins < 12; ++spins) {
+                        v = __hip_atomic_load(ticket, T5VQ_RLX_AGENT);
+                        if (v >= 2) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (v >= 2) {
+                        role = 2;
+                    } else {
+                        const unsigned old2 = __hip_atomic_fetch_add(ticket, 16u, T5VQ_RLX_AGENT);
+                        role = old2 >= 2 ? 2 : 0;   // the partner arrived after the last poll: it does its half only
+                    }
+                    if (role == 2) __hip_atomic_store(ticket, 0u, T5VQ_RLX_AGENT);
+                } else {                  // second: 1 = the partner is (or was) polling, 17 = it left
+                    role = old == 1 ? 2 : 1;
+                    if (role == 1) __hip_atomic_store(ticket, 0u, T5VQ_RLX_AGENT);
+                }
+            } else {
+                role = old == static_cast<unsigned>(S - 1) ? 1 : 0;
+                if (role) __hip_atomic_store(ticket, 0u, T5VQ_RLX_AGENT);   // reset for the next launch
+            }
+            s_misc[0] = role;
         }
         __syncthreads();
-        if (!s_misc[0]) return;
+        const int role = s_misc[0];
+        if (!role) return;
         if (mine) {
             for (int s = 0; s < S; ++s) {
                 if (s == split) continue;
@@ -529,73 +541,155 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
                 key = o < key ? o : key;
             }
         }
+        if (role == 2) {
+            g_cnt = SM_TOK / 2;
+            g_lo = split * g_cnt;
+        }
     }
     if (tid < SM_TOK) {
         int code = -1;
-        if (mine) {
+        if (mine && tid >= g_lo && tid < g_lo + g_cnt) {
             code = key_index(key);
             code = code < 0 ? 0 : (code > K - 1 ? K - 1 : code);
             if (a.idx_out) a.idx_out[my_tok] = code;
         }
-        s_code[tid] = code;
+        s_code[tid] = code;   // -1: not this workgroup's to finish
     }
     __syncthreads();
     T5VQ_STAMP(4);
 
-    // ---- gather + straight-through + loss terms: wave w takes tokens 8 w .. 8 w + 7, all rows requested at once
-    {
-        const f32x4* xr[8];
-        f32x4 xq[8][NCH], qq[8][NCH];
-        int codes[8];
+    // ---- gather + straight-through + loss terms: wave w takes cnt consecutive tokens, all rows requested at once.
+    // What another workgroup waits for (loss terms, codes) leaves first and is signalled before the bulk stores go out.
+    const int cnt = g_cnt / 4;   // 8 or 4 tokens per wave
+    f32x4 xq[8][NCH], qq[8][NCH];
+    int codes[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = tok_base + 8 * wave + i;
-            codes[i] = s_code[8 * wave + i];
-            const int tc = t < N ? t : N - 1;
-            const int cc_ = codes[i] < 0 ? 0 : codes[i];
-            xr[i] = reinterpret_cast<const f32x4*>(a.x + static_cast<size_t>(tc) * D);
-            const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + static_cast<size_t>(cc_) * D);
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        const int pos = g_lo + cnt * wave + i;
+        const int t = tok_base + pos;
+        codes[i] = s_code[pos];
+        const int tc = t < N ? t : N - 1;
+        const int cc_ = codes[i] < 0 ? 0 : codes[i];
+        const f32x4* xrow = reinterpret_cast<const f32x4*>(a.x + static_cast<size_t>(tc) * D);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + static_cast<size_t>(cc_) * D);
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                xq[i][j] = xr[i][j * 64 + lane];
-                qq[i][j] = wr[j * 64 + lane];
-            }
+        for (int j = 0; j < NCH; ++j) {
+            xq[i][j] = xrow[j * 64 + lane];
+            qq[i][j] = wr[j * 64 + lane];
         }
-        float* trow = wl;   // the wave's staging area is free now: transposition row for the embed_sum flush
+    }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = tok_base + 8 * wave + i;
-            if (t >= N) continue;   // wave-uniform
-            const size_t rowoff = static_cast<size_t>(t) * D;
-            float lacc = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        const int t = tok_base + g_lo + cnt * wave + i;
+        if (t >= N) continue;   // wave-uniform
+        float lacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c4 = j * 64 + lane;
-                const f32x4 df = qq[i][j] - xq[i][j];
-                if (a.out_ste) reinterpret_cast<f32x4*>(a.out_ste + rowoff)[c4] = xq[i][j] + df;
-                if (a.out_q) reinterpret_cast<f32x4*>(a.out_q + rowoff)[c4] = qq[i][j];
-                if (a.out_diff) reinterpret_cast<f32x4*>(a.out_diff + rowoff)[c4] = df;
-                lacc = fmaf(df.x, df.x, lacc);
-                lacc = fmaf(df.y, df.y, lacc);
-                lacc = fmaf(df.z, df.z, lacc);
-                lacc = fmaf(df.w, df.w, lacc);
-            }
-            if (a.loss_terms) {
-                lacc = wave_sum(lacc);
-                if (lane == 0)
-                    __hip_atomic_store((gu32*)(a.loss_terms + t), __float_as_uint(lacc), T5VQ_RLX_AGENT);
-            }
-            if (a.embed_sum) {
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) reinterpret_cast<f32x4*>(trow)[j * 64 + lane] = xq[i][j];
-                float* dst = a.embed_sum + static_cast<size_t>(codes[i]) * D;
-#pragma unroll
-                for (int mcol = 0; mcol < NCH * 4; ++mcol) atomicAdd(dst + mcol * 64 + lane, trow[mcol * 64 + lane]);
+        for (int j = 0; j < NCH; ++j) {
+            const f32x4 df = qq[i][j] - xq[i][j];
+            lacc = fmaf(df.x, df.x, lacc);
+            lacc = fmaf(df.y, df.y, lacc);
+            lacc = fmaf(df.z, df.z, lacc);
+            lacc = fmaf(df.w, df.w, lacc);
+        }
+        if (a.loss_terms) {
+            lacc = wave_sum(lacc);
+            if (lane == 0) {
+                __hip_atomic_store((gu32*)(a.loss_terms + t), __float_as_uint(lacc), T5VQ_RLX_AGENT);
+                if (a.scalars) __hip_atomic_store((gu32*)(a.codes + t), static_cast<unsigned>(codes[i]), T5VQ_RLX_AGENT);
             }
         }
     }
-    // counts: one atomic per (workgroup, code) -- the 32 tokens are grouped in LDS by wave 0
-    if (a.counts && wave == 0) {
+    int last = 0;
+    if (a.scalars) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its terms and codes have left
+        __syncthreads();
+        if (tid == 0) {
+            // tokens this workgroup finished; the launch is complete when all N are (a workgroup whose half lies beyond
+            // the batch adds nothing and cannot be last)
+            int n_here = N - tok_base - g_lo;
+            n_here = n_here < 0 ? 0 : (n_here > g_cnt ? g_cnt : n_here);
+            int l = 0;
+            if (n_here > 0) {
+                const unsigned old =
+                    __hip_atomic_fetch_add((gu32*)a.done_ticket, static_cast<unsigned>(n_here), T5VQ_RLX_AGENT);
+                l = old + static_cast<unsigned>(n_here) == static_cast<unsigned>(N);
+            }
+            if (l) __hip_atomic_store((gu32*)a.done_ticket, 0u, T5VQ_RLX_AGENT);
+            s_misc[2] = l;
+        }
+        __syncthreads();
+        last = s_misc[2];
+    }
+    if (last) {
+        // ---- the call's scalars, by the workgroup that signalled last (before its own bulk stores: the sc1 loads below
+        // would otherwise wait behind them): every loss term and every code was stored sc1 and drained before its
+        // workgroup's signal, and is read back with sc1 loads only (no acquire, no counts in global memory)
+        T5VQ_STAMP(6);
+        __syncthreads();
+        int* hist = reinterpret_cast<int*>(lds);           // [K] in the staging area (the host checks that it fits)
+        for (int k = tid; k < K; k += 256) hist[k] = 0;
+        __syncthreads();
+        {
+            const long long n4 = N >> 2;
+            for (long long q0 = tid; q0 < n4; q0 += 1024) {
+                f32x4 u[4];
+                const float* cp = reinterpret_cast<const float*>(a.codes);
+                const bool k1 = q0 + 256 < n4, k2 = q0 + 512 < n4, k3 = q0 + 768 < n4;
+                load4_sc1(cp + 4 * q0, cp + 4 * (q0 + 256), cp + 4 * (q0 + 512), cp + 4 * (q0 + 768), true, k1, k2, k3, u);
+                const bool have[4] = {true, k1, k2, k3};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (!have[m]) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(hist + __float_as_int(u[m][e]), 1);
+                }
+            }
+            const int tl = static_cast<int>(n4 << 2) + tid;
+            if (tl < N) atomicAdd(hist + static_cast<int>(__hip_atomic_load((const gu32*)a.codes + tl, T5VQ_RLX_AGENT)), 1);
+        }
+        __syncthreads();
+        const double ent = entropy_as_1024(hist, K, a.n_tokens, s_red);
+        const double lsum = a.loss_terms ? sum_terms_as_1024(a.loss_terms, N, s_red) : 0.0;
+        if (a.counts)
+            for (int k = tid; k < K; k += 256) a.counts[k] = static_cast<float>(hist[k]);
+        if (tid == 0) {
+            const float m = a.loss_terms ? __fdiv_rn(static_cast<float>(lsum), a.loss_denom) : 0.f;
+            const float cm = __fmul_rn(a.cc, m);
+            a.scalars[0] = a.plain_variant ? __fadd_rn(m, cm) : cm;
+            a.scalars[1] = expf(static_cast<float>(-ent));
+            a.scalars[2] = 0.f;
+            a.scalars[3] = m;
+        }
+        T5VQ_STAMP(7);
+    }
+    // the bulk of the output
+    float* trow = wl;   // the wave's staging area is free now: transposition row for the embed_sum flush
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        const int t = tok_base + g_lo + cnt * wave + i;
+        if (t >= N) continue;
+        const size_t rowoff = static_cast<size_t>(t) * D;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c4 = j * 64 + lane;
+            const f32x4 df = qq[i][j] - xq[i][j];
+            if (a.out_ste) reinterpret_cast<f32x4*>(a.out_ste + rowoff)[c4] = xq[i][j] + df;
+            if (a.out_q) reinterpret_cast<f32x4*>(a.out_q + rowoff)[c4] = qq[i][j];
+            if (a.out_diff) reinterpret_cast<f32x4*>(a.out_diff + rowoff)[c4] = df;
+        }
+        if (a.embed_sum) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) reinterpret_cast<f32x4*>(trow)[j * 64 + lane] = xq[i][j];
+            float* dst = a.embed_sum + static_cast<size_t>(codes[i]) * D;
+#pragma unroll
+            for (int mcol = 0; mcol < NCH * 4; ++mcol) atomicAdd(dst + mcol * 64 + lane, trow[mcol * 64 + lane]);
+        }
+    }
+    // counts (a call without fused scalars): one atomic per (workgroup, code) -- the tokens are grouped in LDS by wave 0
+    if (a.counts && !a.scalars && wave == 0) {
         const int mine_c = lane < SM_TOK ? s_code[lane] : -1;
         unsigned long long m = 0;
         for (int t = 0; t < SM_TOK; ++t)
@@ -604,42 +698,6 @@ __global__ __launch_bounds__(256, 1) void small_fwd_kernel(const SmallArgs a) {
             atomicAdd(a.counts + mine_c, static_cast<float>(__popcll(m)));
     }
     T5VQ_STAMP(5);
-    if (!a.scalars) return;
-
-    // ---- the call's scalars, by the workgroup whose gather finishes last
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its loss terms and count atomics have left
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned n_tok_tiles = static_cast<unsigned>((N + SM_TOK - 1) / SM_TOK);
-        const unsigned old = __hip_atomic_fetch_add((gu32*)a.done_ticket, 1u, T5VQ_RLX_AGENT);
-        const int last = old == n_tok_tiles - 1;
-        if (last) {
-            __hip_atomic_store((gu32*)a.done_ticket, 0u, T5VQ_RLX_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the counts were written by atomics
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_misc[2] = last;
-    }
-    __syncthreads();
-    if (!s_misc[2]) return;
-    T5VQ_STAMP(6);
-    const double ent = entropy_as_1024(a.counts, K, a.n_tokens, s_red);
-    const double lsum = a.loss_terms ? sum_terms_as_1024(a.loss_terms, N, s_red) : 0.0;
-    // every thread has read its counts (the barriers inside the two sums): copy them out if asked, and leave the state
-    // block's counts zeroed for the next call
-    for (int k = tid; k < K; k += 256) {
-        if (a.counts_out) a.counts_out[k] = __uint_as_float(__hip_atomic_load((const gu32*)(a.counts + k), T5VQ_RLX_AGENT));
-        if (a.reset_counts) a.counts[k] = 0.f;
-    }
-    if (tid == 0) {
-        const float m = a.loss_terms ? __fdiv_rn(static_cast<float>(lsum), a.loss_denom) : 0.f;
-        const float cm = __fmul_rn(a.cc, m);
-        a.scalars[0] = a.plain_variant ? __fadd_rn(m, cm) : cm;
-        a.scalars[1] = expf(static_cast<float>(-ent));
-        a.scalars[2] = 0.f;
-        a.scalars[3] = m;
-    }
-    T5VQ_STAMP(7);
 }
 
 
@@ -679,14 +737,6 @@ bool small_shape(int64_t N, int64_t K, int64_t D) {
            ((N + 127) / 128) * ((K + 127) / 128) < 256 && plan_small(N, K, &p);
 }
 
-int g_small_pd() {   // prefetch distance in chunks (register sets): T5VQ_SMALL_PD = 2 | 4, for A/B timing
-    static const int pd = [] {
-        const char* e = getenv("T5VQ_SMALL_PD");
-        return (e && e[0] == '4') ? 4 : 2;
-    }();
-    return pd;
-}
-
 template <int NT, int PD, int NCH>
 int launch_small_t(const SmallArgs& a, const SmallPlan& plan, hipStream_t stream) {
     using C = SmallCfg<NT, PD>;
@@ -720,7 +770,7 @@ extern "C" {
 
 int64_t t5vq_small_state_bytes(int64_t K) {
     if (K < 0) return 0;
-    return align_up(STATE_TICKET_BYTES + 4 * align_up(K, 4), 256);
+    return align_up(STATE_TICKET_BYTES, 256);   // the tickets only (K: room to grow without touching callers)
 }
 
 int t5vq_vq_forward_small_supported(int64_t N, int64_t K, int64_t D) { return small_shape(N, K, D) ? 1 : 0; }
@@ -738,7 +788,7 @@ int t5vq_vq_forward_small_f32(const float* x, const float* w, const float* xx_in
     T5VQ_I_REQUIRE((!out_ste || aligned16(out_ste)) && (!out_q || aligned16(out_q)) && (!out_diff || aligned16(out_diff)),
                    "outputs must be 16-byte aligned");
     T5VQ_I_REQUIRE(workspace_bytes >= t5vq_forward_workspace_bytes(N, K), "workspace smaller than t5vq_forward_workspace_bytes(N, K)");
-    T5VQ_I_REQUIRE(!scalars || K % 4 == 0, "scalars in the same launch need K % 4 == 0");
+    T5VQ_I_REQUIRE(!scalars || (K % 4 == 0 && K <= 16384), "scalars in the same launch need K % 4 == 0 and K <= 16384");
     T5VQ_I_REQUIRE(!scalars || !embed_sum, "scalars in the same launch are for calls without an EMA update");
     SmallPlan plan;
     plan_small(N, K, &plan);
@@ -771,21 +821,17 @@ int t5vq_vq_forward_small_f32(const float* x, const float* w, const float* xx_in
     a.scalars = scalars;
     a.n_tokens = static_cast<float>(N), a.loss_denom = loss_denom, a.cc = commitment_cost;
     a.plain_variant = plain_variant;
-    if (scalars) {   // the counts of the call live in the state block (zero between calls) and are copied out if asked
-        a.counts = reinterpret_cast<float*>(st + STATE_TICKET_BYTES);
-        a.reset_counts = 1;
-        a.counts_out = counts;
-    } else {
-        a.counts = counts;
-        if (counts) T5VQ_I_CHECK_HIP(hipMemsetAsync(counts, 0, static_cast<size_t>(K) * 4, stream));
+    a.counts = counts;
+    if (scalars) {   // the counts come out of the last workgroup's LDS histogram: nothing to zero
+        a.codes = reinterpret_cast<int*>(base + off_xx);
+    } else if (counts) {
+        T5VQ_I_CHECK_HIP(hipMemsetAsync(counts, 0, static_cast<size_t>(K) * 4, stream));
     }
     if (embed_sum) T5VQ_I_CHECK_HIP(hipMemsetAsync(embed_sum, 0, static_cast<size_t>(K) * D * 4, stream));
 #ifdef T5VQ_SMALL_STAMPS
     a.stamps = g_stamps;
 #endif
-    const int pd = g_small_pd();
-    if (plan.nt == 2) return pd == 4 ? launch_small_nch<2, 4>(a, plan, stream) : launch_small_nch<2, 2>(a, plan, stream);
-    return pd == 4 ? launch_small_nch<1, 4>(a, plan, stream) : launch_small_nch<1, 2>(a, plan, stream);
+    return plan.nt == 2 ? launch_small_nch<2, 2>(a, plan, stream) : launch_small_nch<1, 2>(a, plan, stream);
 }
 
 #ifdef T5VQ_SMALL_STAMPS

@@ -159,12 +159,41 @@ Tensor vq_finalize(const OptTensor& cs, const OptTensor& ema_w, const OptTensor&
 // vq_step = the whole module call on one GPU: vq_forward then vq_finalize, one dispatcher crossing.
 // Returns (ste, idx, diff?, q?, scalars, unsettled?); loss / perplexity are scalars[0..1] -- the 0-dim tensors over them
 // are made by the Python caller (vqvae._scalar_of): outputs that alias each other would break the schema's promise.
+//
+// small_state (optional): a zeroed block of t5vq_small_state_bytes(K) bytes that only calls ordered after one another
+// share (the module keeps one).  With it, a call WITHOUT an EMA update (evaluation, or the plain variant) on a small
+// problem (t5vq_vq_forward_small_supported) is ONE launch: t5vq_vq_forward_small_f32 writes the scalars itself.
 std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_step(
     const Tensor& x, const Tensor& w, const OptTensor& ranges, const OptTensor& xx, const OptTensor& ee,
     const OptTensor& cs, const OptTensor& ema_w, int64_t loss_kind, bool filtered, bool want_diff, bool want_q,
     double loss_denom, double decay, double one_minus_decay, double epsilon, double k_epsilon, double commitment_cost,
-    bool plain_variant, bool update, const OptTensor& ee_out) {
+    bool plain_variant, bool update, const OptTensor& ee_out, const OptTensor& small_state) {
     const c10::DeviceGuard guard(x.device());
+    if (!update && small_state.has_value() && small_state->defined() && !ranges.has_value() && !filtered &&
+        loss_kind == T5VQ_LOSS_MSE && x.dim() == 2 && w.dim() == 2 && w.size(0) % 4 == 0 && w.size(0) <= 16384 &&
+        t5vq_vq_forward_small_supported(x.size(0), w.size(0), x.size(1))) {
+        need(x, "x", at::kFloat, 2), need(w, "w", at::kFloat, 2), need(*small_state, "small_state", at::kByte);
+        const int64_t N = x.size(0), D = x.size(1), K = w.size(0);
+        TORCH_CHECK(w.size(1) == D, "x and w disagree on D");
+        TORCH_CHECK(small_state->numel() >= t5vq_small_state_bytes(K), "small_state smaller than t5vq_small_state_bytes(K)");
+        if (xx.has_value()) TORCH_CHECK(need(*xx, "xx").numel() == N, "xx must hold ", N, " row norms");
+        if (ee.has_value()) TORCH_CHECK(need(*ee, "ee").numel() == t5vq_padded_codes(K), "ee must be the padded |e|^2 buffer");
+        same_device(x, w, "w"), same_device(x, xx, "xx"), same_device(x, ee, "ee"), same_device(x, small_state, "small_state");
+        const auto f32 = x.options();
+        Tensor ste = at::empty_like(x), idx = at::empty({N}, f32.dtype(at::kLong)), scalars = at::empty({4}, f32);
+        OptTensor diff, q;
+        if (want_diff) diff = at::empty_like(x);
+        if (want_q) q = at::empty_like(x);
+        const int64_t ws_bytes = t5vq_forward_workspace_bytes(N, K);
+        Tensor ws = at::empty({ws_bytes}, f32.dtype(at::kByte));
+        ok(t5vq_vq_forward_small_f32(x.data_ptr<float>(), w.data_ptr<float>(), ptr(xx), ptr(ee), N, K, D, ws.data_ptr(),
+                                     ws_bytes, small_state->data_ptr(), ste.data_ptr<float>(), ptr(q), ptr(diff),
+                                     idx.data_ptr<int64_t>(), nullptr, nullptr, nullptr, scalars.data_ptr<float>(),
+                                     static_cast<float>(loss_denom), static_cast<float>(commitment_cost),
+                                     plain_variant ? 1 : 0, stream_of(x)),
+           "vq_step (single launch)");
+        return {ste, idx, diff, q, scalars, OptTensor()};
+    }
     Fwd r = forward_impl(x, w, ranges, xx, ee, loss_kind, filtered, want_diff, want_q, update, false);
     const OptTensor wopt = update ? OptTensor(w) : OptTensor();
     Tensor scalars = finalize_impl(cs, ema_w, wopt, r.stats, x.size(0), w.size(0), x.size(1), update, false, x.size(0),
@@ -284,7 +313,7 @@ TORCH_LIBRARY(t5vq, m) {
     m.def("vq_step(Tensor x, Tensor(c!) w, Tensor? ranges, Tensor? xx, Tensor? ee, Tensor(a!)? cluster_size, "
           "Tensor(b!)? ema_w, int loss_kind, bool filtered, bool want_diff, bool want_q, float loss_denom, float decay, "
           "float one_minus_decay, float epsilon, float k_epsilon, float commitment_cost, bool plain_variant, bool update, "
-          "Tensor(d!)? ee_out) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
+          "Tensor(d!)? ee_out, Tensor(e!)? small_state) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
     m.def("ste_backward(Tensor? g_out, Tensor diff, Tensor? g_loss, float coef) -> Tensor");
     m.def("scatter_rows(Tensor rows, Tensor idx, Tensor? scale_dev, float scale_host, int K) -> Tensor");
     m.def("cosine_backward(Tensor x, Tensor q, Tensor? g_out, Tensor? g_loss, float coef_x, float coef_q, "

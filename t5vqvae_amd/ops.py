@@ -456,12 +456,14 @@ def fused_finalize(cluster_size, ema_w, w, stats, n_local: int, k: int, d: int, 
 
 def fused_step(x, w, ranges, loss: str, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False,
                want_diff=False, want_q=False, loss_denom: float, decay: float, one_minus_decay: float, epsilon: float,
-               k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool, ee_out=None):
+               k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool, ee_out=None,
+               small_state=None):
     """(ste, idx, diff | None, q | None, scalars, unsettled | None): the whole module call on one GPU behind one op
-    (t5vq::vq_step = vq_forward + vq_finalize); scalars = [loss, perplexity, n, raw latent loss]."""
+    (t5vq::vq_step = vq_forward + vq_finalize); scalars = [loss, perplexity, n, raw latent loss].  ``small_state`` (a
+    block from ``small_state()``): calls without an EMA update on small problems then take ONE launch."""
     return _lib.load_torch_ops().vq_step(x, w, ranges, xx, ee, cluster_size, ema_w, LOSS_KINDS[loss], filtered,
                                          want_diff, want_q, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
-                                         commitment_cost, plain_variant, update, ee_out)
+                                         commitment_cost, plain_variant, update, ee_out, small_state)
 
 
 def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: bool = True):

@@ -50,6 +50,11 @@ def _filter_state(module):
 _EE_STATE = weakref.WeakKeyDictionary()
 
 
+# State block of the single-launch small-shape forward (tickets; zeroed once, left zeroed by every launch), one per
+# module and device: calls of one module are ordered, calls of different modules may overlap.
+_SMALL_STATE = weakref.WeakKeyDictionary()
+
+
 class _Plan:
     """Per-call configuration handed to the autograd function (plain Python, no tensors)."""
     __slots__ = ("ema", "training", "cc", "decay", "eps", "loss", "batch", "group", "world_tokens", "module", "xx",
@@ -156,6 +161,11 @@ class _QuantizerBase(nn.Module):
     # fixed-point sums (t5vq_embed_sum_fixed_f32): bit-reproducible from run to run and for any token sharding, and
     # exact up to one final rounding; costs one more pass over x.
     deterministic = False
+    # True: small problems (fewer than 256 tiles of 128 x 128, D % 256 == 0) without an EMA update -- evaluation, or the
+    # plain variant -- take ONE launch (t5vq_vq_forward_small_f32): same results bit for bit.  Off by default: measured
+    # at C2 it runs level with the three-launch chain (45.0 against 45.7 us back to back), so the
+    # default stays the path with the longer record.
+    small_forward = False
     index_mode = "reference"     # disentangled mode: "reference" = slice-relative indices used as rows (the
     #                              reference's behaviour, vqvae/vqvae.py:116-119) | "absolute" = start + argmin
 
@@ -297,10 +307,18 @@ class _QuantizerBase(nn.Module):
         dims = (n_total, d, k, batch)
 
         if not bucketed and not fixed and plan.group is None:        # the whole call behind one op
+            small = None
+            if (self.small_forward and not update and ranges is None and mse and not use_filter
+                    and ops.small_supported(n, k, d)):
+                ent = _SMALL_STATE.get(self)
+                if ent is not None and ent.device == dev:
+                    small = ent
+                elif not torch.cuda.is_current_stream_capturing():    # never allocated (and zeroed) inside a capture
+                    small = _SMALL_STATE[self] = ops.small_state(k, dev)
             ste, idx, diff, q, scalars, ovf = ops.fused_step(
                 x, w, ranges, plan.loss, xx=plan.xx, ee=ee, cluster_size=cs, ema_w=ema_w, filtered=use_filter,
                 want_diff=want_diff, want_q=want_q, loss_denom=denom, update=update, ee_out=ee if update else None,
-                **hyper)
+                small_state=small, **hyper)
             if ovf is not None:
                 self._note_unsettled(ovf, n)
             self._last_scalars = scalars

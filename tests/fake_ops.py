@@ -23,6 +23,14 @@ def gather_blocks(n):
     return n if n < 32768 else (n + 63) // 64
 
 
+def small_supported(n, k, d):
+    return False          # the stand-in has no single-launch form: host-logic tests take the chain
+
+
+def small_state(k, device):
+    return torch.zeros(16, dtype=torch.uint8, device=device)
+
+
 def row_sqnorms(x, w):
     xx = None if x is None else (x * x).sum(1)
     ee = None
@@ -212,7 +220,7 @@ def fused_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum,
 
 def fused_step(x, w, ranges, loss, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False, want_diff=False,
                want_q=False, loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
-               update, ee_out=None):
+               update, ee_out=None, small_state=None):
     ste, idx, diff, q, stats, ovf = fused_forward(x, w, ranges, loss, xx=xx, ee=ee, filtered=filtered,
                                                   want_diff=want_diff, want_q=want_q, want_embed_sum=update)
     scalars = fused_finalize(cluster_size, ema_w, w if update else None, stats, x.shape[0], w.shape[0], x.shape[1],
