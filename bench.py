@@ -681,6 +681,34 @@ def run_rank(args):
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         dist_info = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
                      "allreduce_ms_per_step": float(ar) / args.steps * 1e3, "allreduce_bytes": 4.0 * (k * d + k + 1)}
+
+        # The exchange inside the step, both forms, and the step with no exchange at all (same module, same tokens, the
+        # statistics left local): what the all-reduce leaves exposed = step - step without exchange.
+        def timed_steps(m, steps):
+            with torch.no_grad():
+                m._embedding.weight.copy_(w), m._ema_w.copy_(ema_w), m._ema_cluster_size.copy_(cs)
+                for _ in range(2):
+                    m(x)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    m(x)
+                barrier()
+                el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            return float(el) / steps * 1e3
+        mod.stats_exchange = "overlap"
+        ms_overlap = timed_steps(mod, args.steps)
+        mod.stats_exchange = "serial"
+        group = mod.process_group
+        mod.process_group = None                      # local statistics only: the step's kernels without the exchange
+        ms_local = timed_steps(mod, args.steps)
+        mod.process_group = group
+        dist_info["exchange"] = {
+            "serial_ms_per_step": ms_per_step, "overlap_ms_per_step": ms_overlap, "no_exchange_ms_per_step": ms_local,
+            "allreduce_exposed_ms_serial": ms_per_step - ms_local, "allreduce_exposed_ms_overlap": ms_overlap - ms_local,
+            "note": "serial = forward -> all-reduce -> finalize on one stream (module default, the headline); overlap = "
+                    "statistics pass -> asynchronous all-reduce under the output pass -> finalize (one more read of x)"}
         if strong and world > 1 and not dry:
             # the SAME workload on one GPU (rank 0 alone, the others wait): the reference point of strong scaling
             if rank == 0:
@@ -713,7 +741,14 @@ def run_rank(args):
             "config": {"workload": desc, "tokens_per_gpu": n, "global_tokens": n * world, "K": k, "D": d,
                        "regime": args.regime, "search": args.search,
                        "parallelism": f"token-sharded x{world}" if use_dist else "single GPU",
-                       "encodings": "indices (dense one-hot excluded, SURVEY 8b)"},
+                       "encodings": "indices (dense one-hot excluded, SURVEY 8b)",
+                       "like_for_like_across_n_gpus": (
+                           "this line's top-level value is config 4 (2^20 tokens in total, strong scaling); compare it with "
+                           "single_gpu_same_workload.value (speedup_vs_single_gpu, parallel_efficiency_vs_single_gpu) and "
+                           "with series.c4_strong of the --gpus 1 line; series.c3_weak is the config-3 point to hold "
+                           "against the --gpus 1 headline") if strong else (
+                           "config 3, 65536 tokens per GPU (weak scaling): compare with series.c3_weak of the --gpus N "
+                           "lines; series.c4_strong is the one-GPU point of the --gpus N headline (config 4)")},
             "roofline": None if dry else search_kernel_roofline(mod, x, n, k, d, args, workload),
             "step_frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (ms_per_step * 1e-3),
             "step_algorithmic_bytes": step_bytes(n, k, d, update),

@@ -119,6 +119,12 @@ class _QuantizerBase(nn.Module):
     # of the plain variant) are scaled by the group size, so that the average equals the single-process gradient on
     # the concatenated batch.  "sum": the caller sums them (or all-reduces with SUM) -- no scaling.
     gradient_reduction = "mean"
+    # Token-sharded exchange of the EMA statistics.  "serial": forward (search, gather + statistics in one pass over x)
+    # -> all-reduce -> finalize, everything on one stream.  "overlap": the statistics pass runs first and alone, the
+    # all-reduce of its head starts at once (async_op) and runs under the second pass, which writes the per-token
+    # outputs (straight-through values, q - x, indices); finalize waits for it.  Same results; costs one more read of x
+    # ("overlap the all-reduce with K2").  bench.py --gpus N times both.
+    stats_exchange = "serial"
 
     def __init__(self):
         super().__init__()
@@ -289,6 +295,9 @@ class _QuantizerBase(nn.Module):
         # shifting the indices by their range start, needs the keys between the search and the gather
         bucketed = ranges is not None and ((not self.bucket_roles and n >= BUCKET_MIN_TOKENS)
                                            or self.index_mode == "absolute")
+        if self.stats_exchange not in ("serial", "overlap"):
+            raise ValueError(f"stats_exchange must be 'serial' or 'overlap', got {self.stats_exchange!r}")
+        overlap = plan.group is not None and self.stats_exchange == "overlap" and not fixed
 
         n_total, batch, world = n, plan.batch, 1
         if plan.group is not None:
@@ -328,7 +337,8 @@ class _QuantizerBase(nn.Module):
         with_es = update and not fixed
         reduce_loss = plan.group is not None
         kd, counts_off, loss_off, terms_off, n_terms = ops.stats_layout(n, k, d, with_es)
-        if not bucketed:
+        work = None
+        if not bucketed and not overlap:
             ste, idx, diff, q, stats, ovf = ops.fused_forward(
                 x, w, ranges, plan.loss, xx=plan.xx, ee=ee, filtered=use_filter, want_diff=want_diff, want_q=want_q,
                 want_embed_sum=with_es, reduce_loss=reduce_loss)
@@ -345,12 +355,19 @@ class _QuantizerBase(nn.Module):
                                                      use_filter=use_filter), ranges)
             # embed_sum wanted and enough tokens: walk them grouped by code (one flush per run of equal codes)
             perm = ops.order_by_code(keys, k) if (with_es and n >= ops.ORDER_MIN_TOKENS) else None
-            ops.gather_stats(x, w, keys, plan.loss, ste=ste, q=q, diff=diff, idx=idx,
-                             counts=stats[counts_off:counts_off + k],
-                             embed_sum=stats[:kd].view(k, d) if kd else None,
-                             loss_partial=stats[terms_off:terms_off + n_terms], perm=perm)
-            if reduce_loss:
+            out = dict(ste=ste, q=q, diff=diff, idx=idx)
+            st_ = dict(counts=stats[counts_off:counts_off + k], embed_sum=stats[:kd].view(k, d) if kd else None,
+                       loss_partial=stats[terms_off:terms_off + n_terms], perm=perm)
+            if overlap:
+                # statistics first; their all-reduce runs under the pass that writes the per-token outputs
+                ops.gather_stats(x, w, keys, plan.loss, **st_)
                 ops.reduce_partials(stats[terms_off:terms_off + n_terms], stats[loss_off:loss_off + 1])
+                work = dist.all_reduce(stats[:loss_off + 1], op=dist.ReduceOp.SUM, group=plan.group, async_op=True)
+                ops.gather_stats(x, w, keys, plan.loss, **out)
+            else:
+                ops.gather_stats(x, w, keys, plan.loss, **out, **st_)
+                if reduce_loss:
+                    ops.reduce_partials(stats[terms_off:terms_off + n_terms], stats[loss_off:loss_off + 1])
 
         esum = max_bits = None
         if fixed:
@@ -363,7 +380,9 @@ class _QuantizerBase(nn.Module):
             esum = ops.embed_sum_fixed(x, idx, max_bits, k)      # idx doubles as keys (index = low word)
             if plan.group is not None:
                 dist.all_reduce(esum, op=dist.ReduceOp.SUM, group=plan.group)
-        if plan.group is not None:
+        if work is not None:
+            work.wait()                      # the current stream waits for the collective's stream; no host wait
+        elif plan.group is not None:
             dist.all_reduce(stats[:loss_off + 1], op=dist.ReduceOp.SUM, group=plan.group)
 
         # q / loss above used the pre-update codebook (vqvae/vqvae.py:128 precedes :131-144)

@@ -139,7 +139,7 @@ def _worker(rank, world, port, q, mode):
     w0, e0 = synth.normal((K, D), 1, 0), synth.normal((K, D), 1, 1)
     st = vo.VQState(w0.clone(), e0.clone(), torch.zeros(K))
     roles = [(0, 200), (150, 400), (256, 512)] if mode == "code_roles" else None
-    if mode == "token":
+    if mode.startswith("token"):
         from t5vqvae_amd import VectorQuantizerEMA
         from t5vqvae_amd.sharded import shard_tokens
         m = VectorQuantizerEMA(K, D, 0.25, decay=0.99).cuda()
@@ -147,6 +147,8 @@ def _worker(rank, world, port, q, mode):
             m._embedding.weight.copy_(w0)
             m._ema_w.copy_(e0)
         shard_tokens(m)
+        if mode == "token_overlap":        # statistics pass -> asynchronous all-reduce under the output pass -> finalize
+            m.stats_exchange = "overlap"
     else:
         from t5vqvae_amd.sharded import CodeShardedVectorQuantizerEMA
         m = CodeShardedVectorQuantizerEMA(K, D, 0.25, decay=0.99, disentanglement=roles is not None).cuda()
@@ -161,7 +163,7 @@ def _worker(rank, world, port, q, mode):
         w_before = st.weight.clone()
         o = vo.faithful_forward(st, x, srl, ema=True, training=True, commitment_cost=0.25,
                                 disentanglement=roles is not None)
-        if mode == "token":
+        if mode.startswith("token"):
             sl = slice(rank * 2, rank * 2 + 2)
             loss, qz, ppl, idx = m(x[sl].cuda())
             ref_idx, ref_q = o.indices.view(4, -1)[sl].reshape(-1), o.quantized[sl]
@@ -173,7 +175,7 @@ def _worker(rank, world, port, q, mode):
                                         None if srl is None else srl)
         assert out == 0 and torch.equal(idx.squeeze(1).cpu(), ref_idx), "index mismatch"
         errs += [rel(loss, o.loss), rel(ppl, o.perplexity), rel(qz, ref_q)]
-    sd = m.state_dict() if mode == "token" else m.full_state_dict()
+    sd = m.state_dict() if mode.startswith("token") else m.full_state_dict()
     errs += [rel(sd["_ema_cluster_size"], st.cluster_size), rel(sd["_ema_w"], st.ema_w),
              rel(sd["_embedding.weight"], st.weight)]
     q.put((rank, max(errs)))
@@ -181,7 +183,7 @@ def _worker(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["token", "code", "code_roles"])
+@pytest.mark.parametrize("mode", ["token", "token_overlap", "code", "code_roles"])
 def test_two_ranks_on_one_gpu_gloo(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

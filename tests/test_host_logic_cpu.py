@@ -79,12 +79,13 @@ def _reference_run(steps, roles=None, training=True):
     return st, outs
 
 
-def _token_sharded_worker(rank, world, port, q, deterministic=False):
+def _token_sharded_worker(rank, world, port, q, deterministic=False, exchange="serial"):
     _init(rank, world, port)
     from t5vqvae_amd import VectorQuantizerEMA
     from t5vqvae_amd.sharded import shard_tokens, broadcast_state
     m = VectorQuantizerEMA(K, D, 0.25, decay=0.99)
     m.deterministic = deterministic
+    m.stats_exchange = exchange
     with torch.no_grad():
         if rank == 0:
             m._embedding.weight.copy_(synth.normal((K, D), 1, 0))
@@ -272,6 +273,12 @@ def _run(worker, *args):
 @pytest.mark.parametrize("deterministic", [False, True])
 def test_token_sharded_equals_single_process_gloo(deterministic):
     _run(_token_sharded_worker, deterministic)
+
+
+def test_token_sharded_overlapped_exchange_equals_single_process_gloo():
+    """stats_exchange="overlap": statistics pass, asynchronous all-reduce, output pass, wait, finalize -- the same
+    results as the serial form (both are held to the oracle on the concatenated batch, replicas bit-identical)."""
+    _run(_token_sharded_worker, False, "overlap")
 
 
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
