@@ -333,6 +333,94 @@ def c5_shard_config(dev, search, iters, check):
     return out
 
 
+C5_ROLE_SETS = {
+    "8_roles_aligned_to_shards": [(i * (C5_CODES // 8), (i + 1) * (C5_CODES // 8)) for i in range(8)],
+    "5_unequal_roles_straddling_shards": [(0, C5_CODES // 10), (C5_CODES // 10, C5_CODES // 3),
+                                          (C5_CODES // 3, C5_CODES // 2 + 5),
+                                          (C5_CODES // 2 + 5, C5_CODES - C5_CODES // 7), (C5_CODES - C5_CODES // 7, C5_CODES)],
+}
+
+
+def c5_grouped_setup(dev, role_set):
+    """One code shard of the GROUPED form of config 5: codes [3 K/8, 4 K/8) of K = 65536, all 65536 tokens, every token
+    restricted to its role's [start, end) range of the whole codebook (vqvae/vqvae.py:110-119)."""
+    import torch
+    from t5vqvae_amd import synth
+    n, kl, d = C5_TOKENS, C5_CODES // 8, 768
+    off = 3 * kl
+    w = synth.normal((kl, d), 1000, 3, device=dev)
+    roles = C5_ROLE_SETS[role_set]
+    rg = synth.role_ranges(n, roles, 77, 0, device=dev).contiguous()
+    # codes of the shard each token may take: its range cut to [off, off + kl)
+    lo, hi = rg[:, 0].clamp(off, off + kl), rg[:, 1].clamp(off, off + kl)
+    flops = 2.0 * d * float((hi - lo).clamp_min(0).sum())
+    # 'uniform' regime: every token sits near a code of its own range (tokens whose range misses the shard: near any code)
+    span = (hi - lo).clamp_min(0)
+    pick = synth.uniform_int(n, 1 << 30, 2000, 5, dev)
+    c = torch.where(span > 0, lo - off + pick % span.clamp_min(1), pick % kl)
+    x = w.index_select(0, c) + synth.normal((n, d), 2000, 0, device=dev) * 0.5
+    return n, kl, d, off, w, x, rg, flops
+
+
+def c5_grouped_shard_config(dev, role_set, search, iters, check):
+    """The ranged search of one code shard (role order on the device + fused distance / argmin over each token's own
+    range), per call; roofline on the grouped flops 2 D sum_i |range_i within the shard|."""
+    import torch
+    from t5vqvae_amd import ops
+    n, kl, d, off, w, x, rg, flops = c5_grouped_setup(dev, role_set)
+    xx, ee = ops.row_sqnorms(x, w)
+
+    def call(mode):
+        order = ops.order_by_range(rg, kl, off)
+        if mode == "scan":
+            return ops.dist_argmin(x, w, xx, ee, rg, code_offset=off, order=order)
+        return ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True)
+
+    def timed(mode):
+        ts = []
+        for i in range(iters + WARMUP_CALLS):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            keys = call(mode)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= WARMUP_CALLS:
+                ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts), min(ts), keys
+
+    med, mn, keys = timed(search)
+    other = "filter" if search == "scan" else "scan"
+    omed, _, okeys = timed(other)
+    out = {"name": f"c5_grouped_shard_{role_set}",
+           "workload": f"one code shard of grouped C5 ({role_set}): codes [{off}, {off + kl}) of {C5_CODES}, N={n} tokens, "
+                       "role order on the device + ranged search, fine-grained entry points, no peer exchange",
+           "search": search, "ms_per_call_median": med, "ms_per_call_min": mn, "vectors_per_s": n / (med * 1e-3),
+           "algorithmic_flops": flops, "flops_rule": "2 D sum over tokens of |range within the shard|",
+           "dense_flops": 2.0 * n * kl * d,
+           "frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (med * 1e-3),
+           "other_search": {"search": other, "ms_per_call_median": omed,
+                            "indices_identical": bool(torch.equal(keys & 0xFFFFFFFF, okeys & 0xFFFFFFFF))}}
+    if check:
+        from oracle import vq_oracle as vo
+        ns = 2048
+        xs, wc, rs = x[:ns].cpu(), w.cpu(), rg[:ns].cpu()
+        dist = vo.distances(xs, wc)                                  # [ns, kl] against the shard's codes
+        codes = torch.arange(off, off + kl)
+        valid = (codes.unsqueeze(0) >= rs[:, :1]) & (codes.unsqueeze(0) < rs[:, 1:])
+        has = valid.any(1)
+        ref_local = torch.where(valid, dist, torch.full_like(dist, float("inf"))).argmin(1)
+        got = keys[:ns].cpu()
+        none = got == 0x7FFFFFFFFFFFFFFF
+        got_local = (got & 0xFFFFFFFF) + rs[:, 0] - off              # the key's index word is slice-relative
+        outside, inside = vo.classify_mismatches(xs[has], wc, got_local[has], ref_local[has])
+        out["parity"] = {"tokens": ns, "tokens_with_codes_in_this_shard": int(has.sum()),
+                         "none_keys_where_the_range_misses_the_shard": bool(torch.equal(none, ~has)),
+                         "idx_mismatch_outside_band": outside, "idx_mismatch_inside_band": inside,
+                         "against": "oracle distances to the shard's codes, argmin over range ∩ shard, slice-relative"}
+    return out
+
+
 def single_gpu_configs(args, dev):
     """Every BASELINE configuration one GPU can hold besides the headline, plus the assignment regimes of c3."""
     import torch
@@ -377,6 +465,8 @@ def single_gpu_configs(args, dev):
         out.append(entry)
         del mod, state, w, ema_w, cs, x
     out.append(c5_shard_config(dev, args.search, args.config_iters, not args.no_cpu_baseline))
+    for role_set in C5_ROLE_SETS:
+        out.append(c5_grouped_shard_config(dev, role_set, args.search, args.config_iters, not args.no_cpu_baseline))
     return out
 
 

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "t5vq_internal.h"
 
@@ -296,6 +297,9 @@ __global__ __launch_bounds__(THREADS, 1) void filter_f16_kernel(
     }
     const int n_tiles = tile_end - tile_begin;
     const int total = n_tiles * n_chunks;
+    // RANGED: none of this split's codes lies in the ranges of this workgroup's tokens -- collect_kernel does not read
+    // the records of a (token, split) whose range misses the split, so nothing is written (workgroup-uniform)
+    if (RANGED && n_tiles <= 0) return;
 
     if (n_tiles > 0) {
         // LDS-DMA staging (global_load_lds_dwordx4): lane L of a wave-instruction fills the 16 bytes at base + 16 L =
@@ -541,7 +545,8 @@ template <int L, int R>   // R scanners per lane (2 only with L = 64: up to 128 
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* __restrict__ ubuf, const float* __restrict__ lbuf,
                                                       const int* __restrict__ cbuf, int N, int K, int n_scanners,
                                                       int exact_keys, const long long* __restrict__ range,
-                                                      long long code_offset, int* __restrict__ pair_tok,
+                                                      long long code_offset, int codes_per_split,
+                                                      int* __restrict__ pair_tok,
                                                       int* __restrict__ pair_code, long long* __restrict__ keys,
                                                       int* __restrict__ tok_list, int* __restrict__ n_list,
                                                       const int* __restrict__ order) {
@@ -550,19 +555,30 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
     // No lane leaves early: the pair counter below is reserved once per WORKGROUP (prefix sums over all its lanes).
     bool active = tok < N;
     const int real = (active && order) ? order[tok] : tok;   // the token: ranges, keys and the two lists are by token
+    int ra = 0, re = K;      // the token's admissible local codes
     if (active && range) {   // a range that misses this codebook slice (other shard / empty): 'none', as the scan leaves it
         const long long a = range[2 * static_cast<size_t>(real)] - code_offset;
         const long long e = range[2 * static_cast<size_t>(real) + 1] - code_offset;
-        if ((e < K ? e : K) <= (a > 0 ? a : 0)) {
+        ra = static_cast<int>(a > 0 ? (a < K ? a : K) : 0);
+        re = static_cast<int>(e < K ? (e > 0 ? e : 0) : K);
+        if (re <= ra) {
             if (s == 0) keys[real] = KEY_NONE;
             active = false;
         }
     }
     const int n_live = active ? n_scanners : 0;   // an inactive token reads nothing and ends up with no candidates
+    // ranged: the scanners of a code split the token's range misses hold no record (their workgroup may have left
+    // without writing any) -- four scanners per split
+    auto live = [&](int sc) {
+        if (sc >= n_live) return false;
+        if (!range) return true;
+        const int lo = (sc >> 2) * codes_per_split;
+        return max(ra, lo) < min(re, lo + codes_per_split);
+    };
     float T = __int_as_float(0x7F800000);
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (s + r * L < n_live) T = fminf(T, ubuf[static_cast<size_t>(s + r * L) * N + tok]);
+        if (live(s + r * L)) T = fminf(T, ubuf[static_cast<size_t>(s + r * L) * N + tok]);
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) T = fminf(T, __shfl_xor(T, o));
     int c[R * KEEP];
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
         for (int i = 0; i < KEEP; ++i) {
             float l = 0.f;
             int ci = -1;
-            if (sc < n_live) {
+            if (live(sc)) {
                 l = lbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
                 ci = cbuf[(static_cast<size_t>(sc) * KEEP + i) * N + tok];
             }
@@ -719,9 +735,29 @@ constexpr int MIN_TILES = 1;
 // code splits: the fewest code tiles per workgroup for which all workgroups still run at once (<= 256), at most
 // MAX_SPLITS.  C1 (12 token tiles, 40 code tiles): 20 splits of 2 tiles, search 113 us; 8 splits of 5 tiles 165 us.
 // (An earlier measurement had more splits slower: that was the one-thread-per-token collect kernel, not the splits.)
-int64_t plan_filter_splits(int64_t N, int64_t K) {
+// Ranged search: a workgroup only visits the code tiles of its tokens' ranges, so how many workgroups do work is not
+// known on the host (one code shard of a disentangled codebook: the tokens of one role in eight, and with one split
+// 32 of 256 workgroups walked all 32 code tiles of the shard while the others had none: 869 us).  The codes are cut
+// into at least RANGED_SPLITS fixed pieces whatever N is; workgroups whose piece misses their tokens' ranges leave
+// after reading the ranges (no scanner records: collect_kernel skips the splits a token's range misses), and the
+// dispatcher hands the others out as compute units free up.  4 pieces: that shard 328 us, whole codebooks of 8192 ..
+// 65536 codes level or up to 1.35x faster; 8 is better on the aligned shard (266 us) and worse elsewhere
+// (tools/experiments/ranged_filter_splits.py, profiles/r3_ranged_filter_splits.txt).
+constexpr int64_t RANGED_SPLITS = 4;
+int64_t plan_filter_splits(int64_t N, int64_t K, bool ranged) {
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
+    if (ranged) {
+        int64_t s = RANGED_SPLITS;
+#ifdef T5VQ_TUNING
+        if (const char* e = getenv("T5VQ_RANGED_SPLITS")) s = atoi(e);
+#endif
+        const int64_t plain = plan_filter_splits(N, K, false);
+        if (s <= plain) return plain;
+        s = s < code_tiles ? s : code_tiles;
+        const int64_t t = (code_tiles + s - 1) / s;
+        return (code_tiles + t - 1) / t;               // no empty splits
+    }
     // the fewest code tiles per workgroup (at least MIN_TILES) for which all workgroups still run at once
     for (int64_t t = MIN_TILES; t < code_tiles; ++t) {
         const int64_t splits = (code_tiles + t - 1) / t;
@@ -737,7 +773,8 @@ extern "C" {
 
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     if (N < 0 || K < 0 || D < 0) return 0;
-    return FilterWorkspace(N, K, D, 4 * plan_filter_splits(N, K)).total;
+    const int64_t a = plan_filter_splits(N, K, false), b = plan_filter_splits(N, K, true);   // the call may be either
+    return FilterWorkspace(N, K, D, 4 * (a > b ? a : b)).total;
 }
 
 int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
@@ -763,7 +800,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     T5VQ_I_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0 &&
                        (reinterpret_cast<uintptr_t>(ee) & 15u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                    "x, w, ee must be 16-byte aligned and the workspace 256-byte aligned");
-    const int64_t splits = plan_filter_splits(N, K);
+    const int64_t splits = plan_filter_splits(N, K, range != nullptr);
     const int64_t scanners = 4 * splits;
     const FilterWorkspace ws(N, K, D, scanners);
     T5VQ_I_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_filter_workspace_bytes(N, K, D)");
@@ -856,7 +893,8 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
                        dim3(static_cast<unsigned>((N * L_ + COLLECT_THREADS - 1) / COLLECT_THREADS)),                   \
                        dim3(COLLECT_THREADS), 0, stream,                                                             \
                        ubuf, lbuf, cbuf, static_cast<int>(N), static_cast<int>(K), static_cast<int>(scanners),      \
-                       exact_keys, rg, static_cast<long long>(code_offset), cnt, cand,                               \
+                       exact_keys, rg, static_cast<long long>(code_offset),                                          \
+                       static_cast<int>(tiles_per_split * CODE_TILE), cnt, cand,                                     \
                        reinterpret_cast<long long*>(keys), tok_list, n_list, order)
     static_assert(4 * MAX_SPLITS <= 128, "collect_kernel: at most 64 lanes per token, two scanners each");
     if (scanners <= 4) { T5VQ_COLLECT(4, 1); }

@@ -209,6 +209,33 @@ def test_filtered_keys_identical_to_scan_with_role_ranges(n, k, d, offset):
         ops.dist_argmin(x, w, xx, ee, None, order=dev_order)        # an order without ranges is a caller's mistake
 
 
+@pytest.mark.parametrize("roles", [[(i * 8192, (i + 1) * 8192) for i in range(8)],
+                                   [(0, 6553), (6553, 21845), (21845, 32773), (32773, 56174), (56174, 65536)],
+                                   [(0, 24576), (32768, 65536)]])
+def test_filtered_ranged_search_on_a_code_shard_where_most_tokens_belong_elsewhere(roles):
+    """One code shard ([24576, 32768) of 65536 codes) of a grouped search: the tokens of most roles have no code here,
+    the code splits of the ranged form leave workgroups without work (they write no scanner records) -- keys equal
+    the scan's, in token order and visited role by role; with no token at all in the shard every key is 'none'."""
+    from t5vqvae_amd import ops
+    n, kl, d, off = 16384 + 77, 8192, 768, 24576
+    w = synth.normal((kl, d), 96, 0, device="cuda")
+    x, _ = synth.clustered(n, w, 0.5, 97)
+    rg = synth.role_ranges(n, roles, 98, 0, device="cuda").contiguous()
+    xx, ee = ops.row_sqnorms(x, w)
+    scan = ops.dist_argmin(x, w, xx, ee, rg, code_offset=off)
+    for order in (None, ops.order_by_range(rg, kl, off)):
+        for exact in (True, False):
+            f = ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg, code_offset=off, order=order, exact_keys=exact)
+            none = scan == 0x7FFFFFFFFFFFFFFF
+            assert torch.equal(none, f == 0x7FFFFFFFFFFFFFFF)
+            if exact:
+                assert torch.equal(scan, f)
+            else:
+                assert torch.equal((scan & 0xFFFFFFFF)[~none], (f & 0xFFFFFFFF)[~none])
+    inside = ((rg[:, 0] < off + kl) & (rg[:, 1] > off))
+    assert torch.equal(inside, scan != 0x7FFFFFFFFFFFFFFF)
+
+
 def test_disentangled_module_filter_equals_scan():
     from t5vqvae_amd import VectorQuantizerEMA
     n, k, d = 8192, 4096, 768

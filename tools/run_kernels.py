@@ -1,6 +1,7 @@
 """Small driver for profiler passes: a few launches of the hot kernels at a BASELINE shape.
 
     python3 tools/run_kernels.py [c3|c1|c2|c4] [reps] [dist|step] [scan|filter|auto]
+    python3 tools/run_kernels.py [ranged8|ranged5] [reps] search [scan|filter]   one code shard of grouped C5, one rank
 """
 import os
 import sys
@@ -18,6 +19,19 @@ search = sys.argv[4] if len(sys.argv) > 4 else "scan"   # the benchmark's headli
 from t5vqvae_amd import _lib  # noqa: E402
 _lib.load().t5vq_set_tuning(int(os.environ.get("T5VQ_TUNE", "0")))
 dev = torch.device("cuda", 0)
+if workload.startswith("ranged"):
+    role_set = [r for r in bench.C5_ROLE_SETS if r.startswith(workload[len("ranged"):] + "_")][0]
+    n, kl, d, off, w, x, rg, flops = bench.c5_grouped_setup(dev, role_set)
+    xx, ee = ops.row_sqnorms(x, w)
+    for _ in range(reps):
+        order = ops.order_by_range(rg, kl, off)
+        if search == "scan":
+            ops.dist_argmin(x, w, xx, ee, rg, code_offset=off, order=order)
+        else:
+            ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True)
+    torch.cuda.synchronize()
+    print(f"done {role_set} {search} algorithmic_flops={flops:.6g}")
+    sys.exit(0)
 n, k, d, update, _ = bench.WORKLOADS[workload]
 w, ema_w, cs, x = bench.build_state(workload, os.environ.get("T5VQ_REGIME", "uniform"), 0, 1, dev)
 if what == "dist":
