@@ -325,13 +325,14 @@ int t5vq_vq_forward_noalloc_f32(const float* x, const float* w, const int64_t* r
  * tiles of 128 x 128, N < T5VQ_SMALL_MAX_TOKENS, D % 256 == 0, D <= 1024; plain search, mse loss.
  * workspace: t5vq_forward_workspace_bytes(N, K) bytes, as for t5vq_vq_forward_f32.
  * state: t5vq_small_state_bytes(K) bytes of device memory that the caller ZEROES ONCE (hipMemset) and then hands,
- *   untouched, to every call (tickets of the hand-offs and the call's counts; each launch leaves it zeroed again, so no
- *   call pays a memset).  Calls that share a state block must not overlap in time (one stream, or otherwise ordered).
+ *   untouched, to every call (the tickets of the hand-offs between workgroups; each launch leaves it zeroed again, so
+ *   no call pays a memset).  Calls that share a state block must not overlap in time (one stream, or otherwise ordered).
  * xx_in, ee_in (nullable) as in t5vq_vq_forward_f32 (a missing ee_in costs a row-norm launch over w).
  * counts, embed_sum (nullable): zeroed by the call (a memset each), then accumulated.  loss_terms (nullable): N floats,
  *   one term per token.  scalars (nullable, needs K % 4 == 0 and no embed_sum): [loss, perplexity, 0, raw latent loss]
- *   as t5vq_ema_cluster_f32 mode 0 writes them from loss_denom / commitment_cost / plain_variant; counts (if given)
- *   then receives a copy of the call's counts and costs no memset. */
+ *   as t5vq_ema_cluster_f32 mode 0 writes them from loss_denom / commitment_cost / plain_variant (K <= 16384); counts
+ *   (if given) is then written once by the last workgroup from its histogram of the codes and costs no memset.
+ * No reference counterpart as a call of its own: it replaces the same lines as the chain it is identical to. */
 #define T5VQ_SMALL_MAX_TOKENS 32768
 int64_t t5vq_small_state_bytes(int64_t K);
 int t5vq_vq_forward_small_supported(int64_t N, int64_t K, int64_t D);
