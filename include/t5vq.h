@@ -364,6 +364,50 @@ int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const 
                              float k_epsilon, float commitment_cost, int plain_variant, int update, float* scalars,
                              float* ee_out, t5vq_stream_t stream);
 
+/* ---- fp16 images made by the producers of the rows (no reference counterpart: the filtered search is an
+ * implementation choice) ------------------------------------------------------------------------------------------
+ * The filtered search works on fp16 images of x and w (every row scaled by a power of two, with its inverse scale and,
+ * for codes, sqrt(|e|^2)).  Its preparation pass makes them from the fp32 rows in every call; these variants let the
+ * kernels that WRITE the rows emit the images, so that pass reads no row a producer has covered:
+ *   code image  (t5vq_code_image_bytes(K, D) bytes, 256-byte aligned, caller-owned, kept between calls): written by
+ *     the codebook update (the _img forms of t5vq_ema_embed_f32 / _fixed_f32 / t5vq_vq_ema_finalize_f32: the image of
+ *     the codebook they have just written, vqvae/vqvae.py:144; D <= 2048), or by a search called with code_image_valid = 0 (it
+ *     makes the image as before, but in the caller's block: an evaluation loop pays for it once).  A search called
+ *     with code_image_valid != 0 reads it and needs ee as an input.  The image must be that of w, bit for bit: the
+ *     caller keeps it only while w is unchanged (the module keys it by the codebook's pointer and version).
+ *   token image (t5vq_token_image_bytes(N, D) bytes, 256-byte aligned): written by t5vq_rmsnorm_sqnorms_img_f32 for the
+ *     x it produces (python_transformers/modeling_t5.py:864-865); a search given one needs xx as an input and ignores
+ *     it when the tokens are visited in role order (order != NULL, or ranges in the composite forward from 1024 tokens).
+ * Images are bit-identical to the ones the search makes itself, so are all results (tests/test_gpu_filter.py).
+ * Every other argument as in the form without _img. */
+int64_t t5vq_code_image_bytes(int64_t K, int64_t D);
+int64_t t5vq_token_image_bytes(int64_t N, int64_t D);
+int t5vq_dist_argmin_filtered_img_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
+                                      const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                                      int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
+                                      int64_t* keys, int32_t* n_overflow, void* code_image, int code_image_valid,
+                                      const void* token_image, t5vq_stream_t stream);
+int t5vq_vq_forward_filtered_img_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                     const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind,
+                                     void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                                     float* out_diff, int64_t* idx_out, float* counts, float* embed_sum,
+                                     float* loss_terms, float* loss_sum, int32_t* n_overflow, void* code_image,
+                                     int code_image_valid, const void* token_image, t5vq_stream_t stream);
+int t5vq_ema_embed_img_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
+                           int64_t D, float decay, float one_minus_decay, float* ee_out, void* code_image,
+                           t5vq_stream_t stream);
+int t5vq_ema_embed_fixed_img_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
+                                 const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
+                                 float* ee_out, void* code_image, t5vq_stream_t stream);
+int t5vq_vq_ema_finalize_img_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
+                                 const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K,
+                                 int64_t D, int64_t n_tokens, float loss_denom, float decay, float one_minus_decay,
+                                 float epsilon, float k_epsilon, float commitment_cost, int plain_variant, int update,
+                                 float* scalars, float* ee_out, void* code_image, t5vq_stream_t stream);
+int t5vq_rmsnorm_sqnorms_img_f32(const float* hidden, const float* gamma, const uint8_t* keep, float scale, float eps,
+                                 int64_t N, int64_t D, float* x_out, float* xx, float* rms, void* token_image,
+                                 t5vq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

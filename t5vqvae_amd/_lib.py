@@ -49,6 +49,13 @@ SIGNATURES = {
     "t5vq_dist_topk_f32": (c_int, [P, P, P, P, I64, I64, I64, I64, P, P]),
     "t5vq_blend_argmin_f32": (c_int, [P, P, c_float, c_float, I64, I64, P, P]),
     "t5vq_rmsnorm_sqnorms_f32": (c_int, [P, P, P, c_float, c_float, I64, I64, P, P, P, P]),
+    "t5vq_rmsnorm_sqnorms_img_f32": (c_int, [P, P, P, c_float, c_float, I64, I64, P, P, P, P, P]),
+    "t5vq_code_image_bytes": (I64, [I64, I64]),
+    "t5vq_token_image_bytes": (I64, [I64, I64]),
+    "t5vq_dist_argmin_filtered_img_f32": (c_int, [P, P, P, P, c_int, P, P, I64, I64, I64, I64, c_int, P, I64, P, P, P,
+                                                  c_int, P, P]),
+    "t5vq_ema_embed_img_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P, P, P]),
+    "t5vq_ema_embed_fixed_img_f32": (c_int, [P, P, P, P, P, I64, I64, c_float, c_float, P, P, P]),
     "t5vq_rmsnorm_backward_blocks": (I64, [I64]),
     "t5vq_rmsnorm_backward_f32": (c_int, [P, P, P, P, c_float, P, I64, I64, P, P, P, P]),
     "t5vq_forward_workspace_bytes": (I64, [I64, I64]),
@@ -64,6 +71,10 @@ SIGNATURES = {
                                              P]),
     "t5vq_vq_ema_finalize_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, I64, c_float, c_float, c_float, c_float,
                                          c_float, c_float, c_int, c_int, P, P, P]),
+    "t5vq_vq_forward_filtered_img_f32": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P, I64, P, P, P, P, P, P, P, P, P,
+                                                 P, c_int, P, P]),
+    "t5vq_vq_ema_finalize_img_f32": (c_int, [P, P, P, P, P, P, I64, I64, I64, I64, c_float, c_float, c_float, c_float,
+                                             c_float, c_float, c_int, c_int, P, P, P, P]),
 }
 
 TORCH_LIB_PATH = os.environ.get("T5VQ_TORCH_LIB") or os.path.join(_HERE, "csrc", "libt5vq_torch.so")
@@ -79,7 +90,7 @@ _torch_ops_error = None
 
 _load_lock = threading.RLock()
 
-ABI_VERSION = 300     # t5vq_version() of the library these signatures were written against (the small-shape forward)
+ABI_VERSION = 310     # t5vq_version() of the library these signatures were written against (image-emitting _img entry points)
 
 
 class T5VQError(RuntimeError):

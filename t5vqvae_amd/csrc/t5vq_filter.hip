@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           long long kpad, float* __restrict__ se, int D,
                                                           int* __restrict__ n_list, int* __restrict__ tshare,
                                                           unsigned row_blocks, T5vqZeroArgs zero, int norm_x,
-                                                          int norm_w, const int* __restrict__ order) {
+                                                          int norm_w, const int* __restrict__ order, int have_x_image) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= row_blocks) {   // the tail of the grid zeroes the caller's buffers: 4096 words per workgroup
         long long i = (static_cast<long long>(blockIdx.x - row_blocks) * 256 + threadIdx.x) * 16;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         const long long token = order ? order[row] : row;
         src = x + token * D; dst = xh + row * D; inv = x_inv + row; norm = xx + token;
         if (lane == 0) tshare[row] = 0x7F800000;   // order image of +inf: no bound yet
+        if (have_x_image) return;                  // the producer of x wrote this row's image (and |x|^2 is given)
     } else {
         row -= n_x;
         if (row >= kpad) return;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
     for (int j = 0; j < NCH; ++j) {
         const int c4 = j * 64 + lane;
         v[j] = (c4 * 4 < D) ? reinterpret_cast<const f32x4*>(src)[c4] : zero4;
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        m = t5vq_absmax4(m, v[j].x, v[j].y, v[j].z, v[j].w);
     }
     float sq = 0.f;
     if (is_w ? norm_w : norm_x) {   // the squared norm, in row_sqnorms_kernel's lane layout and order (bit-identical to it)
@@ -158,24 +159,13 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
     if (is_w && lane == 0) se[row] = sqrtf(sq);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    int e = ((__float_as_int(m) >> 23) & 0xFF) - 127;   // floor(log2 m) for normal m
-    int sexp = 14 - e;
-    if (m == 0.f || e < -100) sexp = 0;                   // all-zero (or denormal) row: no scaling
-    sexp = sexp > 100 ? 100 : (sexp < -100 ? -100 : sexp);
-    const float scale = __int_as_float((sexp + 127) << 23);
-    if (lane == 0) *inv = __int_as_float((127 - sexp) << 23);
+    float invv;
+    const float scale = t5vq_image_scale(m, &invv);
+    if (lane == 0) *inv = invv;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c4 = j * 64 + lane;
-        if (c4 * 4 < D) {
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 o;
-            o.x = static_cast<_Float16>(v[j].x * scale);
-            o.y = static_cast<_Float16>(v[j].y * scale);
-            o.z = static_cast<_Float16>(v[j].z * scale);
-            o.w = static_cast<_Float16>(v[j].w * scale);
-            reinterpret_cast<f16x4*>(dst)[c4] = o;
-        }
+        if (c4 * 4 < D) t5vq_image_store4(dst, c4, v[j].x, v[j].y, v[j].z, v[j].w, scale);
     }
 }
 
@@ -783,15 +773,44 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     T5vqZeroArgs zero = {};
     return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, order, N, K, D, code_offset, exact_keys,
-                                              workspace, workspace_bytes, keys, n_overflow, zero,
+                                              workspace, workspace_bytes, keys, n_overflow, zero, nullptr, 0, nullptr,
                                               static_cast<hipStream_t>(stream_));
+}
+
+int64_t t5vq_code_image_bytes(int64_t K, int64_t D) {
+    if (K <= 0 || D <= 0) return 0;
+    return t5vq_align256(2 * K * D) + 2 * t5vq_align256(4 * t5vq_padded_codes(K));
+}
+int64_t t5vq_token_image_bytes(int64_t N, int64_t D) {
+    if (N <= 0 || D <= 0) return 0;
+    return t5vq_align256(2 * N * D) + t5vq_align256(4 * N);
+}
+int t5vq_dist_argmin_filtered_img_f32(const float* x, const float* w, float* xx, float* ee, int compute_norms,
+                                      const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
+                                      int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
+                                      int64_t* keys, int32_t* n_overflow, void* code_image, int code_image_valid,
+                                      const void* token_image, t5vq_stream_t stream_) {
+    T5vqZeroArgs zero = {};
+    return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, order, N, K, D, code_offset, exact_keys,
+                                              workspace, workspace_bytes, keys, n_overflow, zero, code_image,
+                                              code_image_valid, token_image, static_cast<hipStream_t>(stream_));
 }
 
 int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
                                        const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
                                        int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
-                                       int64_t* keys, int32_t* n_overflow, T5vqZeroArgs zero, hipStream_t stream) {
+                                       int64_t* keys, int32_t* n_overflow, T5vqZeroArgs zero, void* code_image,
+                                       int code_image_valid, const void* token_image, hipStream_t stream) {
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
+    if (order) token_image = nullptr;   // the search walks image rows in role order: an image in token order is no use
+    const bool have_w_image = code_image && code_image_valid;
+    const bool have_x_image = token_image != nullptr;
+    T5VQ_I_REQUIRE(!have_w_image || compute_norms == 0 || compute_norms == 3,
+                   "a valid code image comes with the codebook's norms: ee must be an input");
+    T5VQ_I_REQUIRE(!have_x_image || compute_norms == 0 || compute_norms == 2,
+                   "a token image comes with the row norms of x: xx must be an input");
+    T5VQ_I_REQUIRE((reinterpret_cast<uintptr_t>(code_image) & 255u) == 0 && (reinterpret_cast<uintptr_t>(token_image) & 255u) == 0,
+                   "image blocks must be 256-byte aligned");
     T5VQ_I_REQUIRE(!order || range, "order is an ordering for the ranged search: range is null");
     T5VQ_I_REQUIRE(compute_norms >= 0 && compute_norms <= 3, "compute_norms must be 0..3");
     T5VQ_I_REQUIRE(N > 0 && K > 0 && N < (1LL << 31) - TOK_TILE && K < (1LL << 31) - 512, "N, K out of range");
@@ -819,6 +838,14 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     float* se = reinterpret_cast<float*>(base + ws.se);
     float* x_inv = reinterpret_cast<float*>(base + ws.xinv);
     float* w_inv = reinterpret_cast<float*>(base + ws.winv);
+    if (code_image) {    // the codebook's image lives in the caller's block (read there, or written there by this call)
+        const T5vqCodeImage im = t5vq_code_image_parts(code_image, K, D);
+        wb = im.rows, w_inv = im.inv, se = im.se;
+    }
+    if (have_x_image) {
+        const T5vqTokenImage im = t5vq_token_image_parts(const_cast<void*>(token_image), N, D);
+        xb = im.rows, x_inv = im.inv;
+    }
     float* ubuf = reinterpret_cast<float*>(base + ws.ubuf);
     float* lbuf = reinterpret_cast<float*>(base + ws.lbuf);
     int* cbuf = reinterpret_cast<int*>(base + ws.cbuf);
@@ -830,7 +857,9 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     const int64_t kpad = t5vq_padded_codes(K);
 
     {
-        const int64_t rows = N + kpad;   // x rows, then w rows and the |e|^2 padding
+        // x rows (with a token image: only their shared-bound slots are reset), then -- unless the codebook's image is
+        // valid -- w rows and the |e|^2 padding
+        const int64_t rows = N + (have_w_image ? 0 : kpad);
         const unsigned row_blocks = static_cast<unsigned>((rows + 3) / 4);
         long long zero_blocks = 0;
         for (int r = 0; r < 3; ++r) {
@@ -846,8 +875,9 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
         const int norm_w = (compute_norms == 1 || compute_norms == 2) ? 1 : 0;
 #define T5VQ_PREP(NCH_)                                                                                          \
     hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
-                       x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee, static_cast<long long>(kpad), se,  \
-                       static_cast<int>(D), n_list, tshare, row_blocks, zero, norm_x, norm_w, order)
+                       x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee,                                   \
+                       static_cast<long long>(have_w_image ? 0 : kpad), se, static_cast<int>(D), n_list, tshare,   \
+                       row_blocks, zero, norm_x, norm_w, order, have_x_image ? 1 : 0)
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }

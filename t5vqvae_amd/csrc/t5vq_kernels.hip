@@ -1469,6 +1469,29 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
     }
 }
 
+// The fp16 image of the code row a wave has just written (t5vq_internal.h; the filtered search of the NEXT call then
+// reads no fp32 codebook row for its preparation): what filter_prep_kernel would make of the row, bit for bit -- the
+// same scale rule on the same values, sqrt of the same |e|^2.  qv: the row in registers, float4 #(lane + 64 j)
+// (D <= 2048: the launcher refuses an image beyond); m: the lane's largest magnitude, sq: |e_row|^2.
+constexpr int IMG_NCH = 8;
+__device__ __forceinline__ void emit_code_image_row(const T5vqCodeImage& img, const f32x4 (&qv)[IMG_NCH], long long row,
+                                                    int D, int lane, float m, float sq) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float invv;
+    const float scale = t5vq_image_scale(m, &invv);
+    if (lane == 0) {
+        img.inv[row] = invv;
+        img.se[row] = sqrtf(sq);
+    }
+    _Float16* dst = img.rows + row * D;
+#pragma unroll
+    for (int j = 0; j < IMG_NCH; ++j) {
+        const int i = lane + 64 * j;
+        if (i < (D >> 2)) t5vq_image_store4(dst, i, qv[j].x, qv[j].y, qv[j].z, qv[j].w, scale);
+    }
+}
+
 // K4b: codebook EMA, one wave per code row
 // ee_out (nullable): |e_row|^2 of the row just written, accumulated in row_sqnorm_wave's lane layout and order from
 // the values in registers -- bit-identical to t5vq_row_sqnorms_f32 run on the new codebook, so the next call need not
@@ -1476,16 +1499,21 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
 __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
                                                         const float* __restrict__ dw, const float* __restrict__ cs,
                                                         int K, int D, float decay, float omd,
-                                                        float* __restrict__ ee_out) {
+                                                        float* __restrict__ ee_out, T5vqCodeImage img, int kpad) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (img.rows && blockIdx.x == 0)   // the image's padding entries: inverse scale 1, sqrt(|e|^2) = +inf
+        for (int r = K + threadIdx.x; r < kpad; r += blockDim.x) {
+            img.inv[r] = 1.0f;
+            img.se[r] = __int_as_float(0x7F800000);
+        }
     if (row >= K) return;
     const float c = cs[row];
     f32x4* e = reinterpret_cast<f32x4*>(ema_w + row * D);
     f32x4* o = reinterpret_cast<f32x4*>(w + row * D);
     const f32x4* s = reinterpret_cast<const f32x4*>(dw + row * D);
-    float sq = 0.f;
-    for (int i = lane; i < (D >> 2); i += 64) {
+    float sq = 0.f, m = 0.f;
+    auto one = [&](int i) {
         const f32x4 a = e[i], b = s[i];
         f32x4 v, q;
         v.x = __fadd_rn(__fmul_rn(a.x, decay), __fmul_rn(omd, b.x));
@@ -1499,7 +1527,24 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
         e[i] = v;
         o[i] = q;
         sq = sq4(q, sq);
+        return q;
+    };
+    if (img.rows) {   // D <= 2048: the row stays in registers for its image
+        f32x4 qv[IMG_NCH];
+#pragma unroll
+        for (int j = 0; j < IMG_NCH; ++j) {
+            const int i = lane + 64 * j;
+            if (i < (D >> 2)) {
+                qv[j] = one(i);
+                m = t5vq_absmax4(m, qv[j].x, qv[j].y, qv[j].z, qv[j].w);
+            }
+        }
+        sq = wave_sum(sq);
+        if (ee_out && lane == 0) ee_out[row] = sq;
+        emit_code_image_row(img, qv, row, D, lane, m, sq);
+        return;
     }
+    for (int i = lane; i < (D >> 2); i += 64) one(i);
     if (ee_out) {
         sq = wave_sum(sq);
         if (lane == 0) ee_out[row] = sq;
@@ -1516,7 +1561,8 @@ __global__ __launch_bounds__(256) void rmsnorm_sqnorms_kernel(const float* __res
                                                               const float* __restrict__ gamma,
                                                               const unsigned char* __restrict__ keep, float scale,
                                                               float eps, int N, int D, float* __restrict__ x_out,
-                                                              float* __restrict__ xx, float* __restrict__ rms_out) {
+                                                              float* __restrict__ xx, float* __restrict__ rms_out,
+                                                              T5vqTokenImage img) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -1537,17 +1583,17 @@ __global__ __launch_bounds__(256) void rmsnorm_sqnorms_kernel(const float* __res
     const float var = __fdiv_rn(ss, static_cast<float>(D));   // x.pow(2).mean(-1)
     const float r = __fsqrt_rn(__fadd_rn(var, eps));           // sqrt(variance + eps)
     if (rms_out && lane == 0) rms_out[row] = r;
-    float s2 = 0.f;
+    float s2 = 0.f, m = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c4 = j * 64 + lane;
         if (c4 * 4 < D) {
             const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4];
-            f32x4 y;
-            y.x = __fmul_rn(g.x, __fdiv_rn(hv[j].x, r));       // weight * (x / sqrt(...))
-            y.y = __fmul_rn(g.y, __fdiv_rn(hv[j].y, r));
-            y.z = __fmul_rn(g.z, __fdiv_rn(hv[j].z, r));
-            y.w = __fmul_rn(g.w, __fdiv_rn(hv[j].w, r));
+            f32x4& y = hv[j];   // the input row is done with: its registers hold the output row from here on
+            y.x = __fmul_rn(g.x, __fdiv_rn(y.x, r));           // weight * (x / sqrt(...))
+            y.y = __fmul_rn(g.y, __fdiv_rn(y.y, r));
+            y.z = __fmul_rn(g.z, __fdiv_rn(y.z, r));
+            y.w = __fmul_rn(g.w, __fdiv_rn(y.w, r));
             if (keep) {
                 const uchar4 m = reinterpret_cast<const uchar4*>(keep + row * D)[c4];
                 y.x = m.x ? __fmul_rn(y.x, scale) : 0.f;
@@ -1560,10 +1606,24 @@ __global__ __launch_bounds__(256) void rmsnorm_sqnorms_kernel(const float* __res
             s2 = fmaf(y.y, y.y, s2);
             s2 = fmaf(y.z, y.z, s2);
             s2 = fmaf(y.w, y.w, s2);
+            m = t5vq_absmax4(m, y.x, y.y, y.z, y.w);
         }
     }
     s2 = wave_sum(s2);
     if (xx && lane == 0) xx[row] = s2;
+    if (img.rows) {   // the row's fp16 image for the filtered search, as filter_prep_kernel would make it
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float invv;
+        const float sc = t5vq_image_scale(m, &invv);
+        if (lane == 0) img.inv[row] = invv;
+        _Float16* dst = img.rows + row * D;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c4 = j * 64 + lane;
+            if (c4 * 4 < D) t5vq_image_store4(dst, c4, hv[j].x, hv[j].y, hv[j].z, hv[j].w, sc);
+        }
+    }
 }
 
 // Backward of the tail.  With gy = g * keep * scale, a = gy * gamma, r = sqrt(mean(h^2) + eps):
@@ -1737,14 +1797,20 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
                                                               const long long* __restrict__ dw,
                                                               const int* __restrict__ max_xx_bits,
                                                               const float* __restrict__ cs, int K, int D, float decay,
-                                                              float omd, float* __restrict__ ee_out) {
+                                                              float omd, float* __restrict__ ee_out, T5vqCodeImage img,
+                                                              int kpad) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (img.rows && blockIdx.x == 0)
+        for (int r = K + threadIdx.x; r < kpad; r += blockDim.x) {
+            img.inv[r] = 1.0f;
+            img.se[r] = __int_as_float(0x7F800000);
+        }
     if (row >= K) return;
     const double inv = ldexp(1.0, -fixed_shift(*max_xx_bits));
     const float c = cs[row];
-    float sq = 0.f;
-    for (int i4 = lane; i4 < (D >> 2); i4 += 64) {   // float4 #i4 per lane: row_sqnorm_wave's layout
+    float sq = 0.f, m = 0.f;
+    auto one = [&](int i4) {   // float4 #i4 per lane: row_sqnorm_wave's layout
         f32x4 q;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1756,7 +1822,24 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
             w[i] = q[e];
         }
         sq = sq4(q, sq);
+        return q;
+    };
+    if (img.rows) {   // D <= 2048: the row stays in registers for its image
+        f32x4 qv[IMG_NCH];
+#pragma unroll
+        for (int j = 0; j < IMG_NCH; ++j) {
+            const int i4 = lane + 64 * j;
+            if (i4 < (D >> 2)) {
+                qv[j] = one(i4);
+                m = t5vq_absmax4(m, qv[j].x, qv[j].y, qv[j].z, qv[j].w);
+            }
+        }
+        sq = wave_sum(sq);
+        if (ee_out && lane == 0) ee_out[row] = sq;
+        emit_code_image_row(img, qv, row, D, lane, m, sq);
+        return;
     }
+    for (int i4 = lane; i4 < (D >> 2); i4 += 64) one(i4);
     if (ee_out) {
         sq = wave_sum(sq);
         if (lane == 0) ee_out[row] = sq;
@@ -2183,7 +2266,7 @@ int launch_dist_self(const float* x, const float* w, const float* xx, const floa
 // ================================================================================================
 extern "C" {
 
-int t5vq_version(void) { return 300; }
+int t5vq_version(void) { return 310; }
 int t5vq_set_tuning(int variant) {
     g_depth2 = variant >= 100000 ? 0 : 1;   // +100000: single staging register set
     variant %= 100000;
@@ -2427,16 +2510,24 @@ int t5vq_ema_cluster_f32(float* cluster_size, const float* counts, const float* 
     return T5VQ_OK;
 }
 
-int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
-                       int64_t D, float decay, float one_minus_decay, float* ee_out, t5vq_stream_t stream) {
+int t5vq_ema_embed_img_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
+                           int64_t D, float decay, float one_minus_decay, float* ee_out, void* code_image,
+                           t5vq_stream_t stream) {
     T5VQ_REQUIRE(ema_w && w && embed_sum && cluster_size, "null pointer");
     T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0 && D % 4 == 0, "K, D out of range");
     T5VQ_REQUIRE(aligned16(ema_w) && aligned16(w) && aligned16(embed_sum), "buffers must be 16-byte aligned");
+    T5VQ_REQUIRE((reinterpret_cast<uintptr_t>(code_image) & 255u) == 0, "code_image must be 256-byte aligned");
+    T5VQ_REQUIRE(!code_image || D <= 2048, "the update writes a code image for D <= 2048 only");
     hipLaunchKernelGGL(ema_embed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),
-                       static_cast<int>(D), decay, one_minus_decay, ee_out);
+                       static_cast<int>(D), decay, one_minus_decay, ee_out, t5vq_code_image_parts(code_image, K, D),
+                       static_cast<int>(t5vq_padded_codes(K)));
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
+}
+int t5vq_ema_embed_f32(float* ema_w, float* w, const float* embed_sum, const float* cluster_size, int64_t K,
+                       int64_t D, float decay, float one_minus_decay, float* ee_out, t5vq_stream_t stream) {
+    return t5vq_ema_embed_img_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, ee_out, nullptr, stream);
 }
 
 int t5vq_max_norm_f32(const float* xx, int64_t N, int32_t* max_xx_bits, t5vq_stream_t stream_) {
@@ -2492,17 +2583,26 @@ int t5vq_embed_sum_fixed_f32(const float* x, const int64_t* keys, const int32_t*
     return T5VQ_OK;
 }
 
-int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
-                             const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
-                             float* ee_out, t5vq_stream_t stream) {
+int t5vq_ema_embed_fixed_img_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
+                                 const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
+                                 float* ee_out, void* code_image, t5vq_stream_t stream) {
     T5VQ_REQUIRE(ema_w && w && embed_sum && max_xx_bits && cluster_size, "null pointer");
     T5VQ_REQUIRE(K > 0 && K < (1LL << 31) && D > 0 && D % 4 == 0, "K, D out of range");
+    T5VQ_REQUIRE(!code_image || (aligned16(w) && (reinterpret_cast<uintptr_t>(code_image) & 255u) == 0),
+                 "code_image must be 256-byte aligned (and w 16-byte aligned)");
+    T5VQ_REQUIRE(!code_image || D <= 2048, "the update writes a code image for D <= 2048 only");
     hipLaunchKernelGGL(ema_embed_fixed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ema_w, w, reinterpret_cast<const long long*>(embed_sum),
                        max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay,
-                       ee_out);
+                       ee_out, t5vq_code_image_parts(code_image, K, D), static_cast<int>(t5vq_padded_codes(K)));
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
+}
+int t5vq_ema_embed_fixed_f32(float* ema_w, float* w, const int64_t* embed_sum, const int32_t* max_xx_bits,
+                             const float* cluster_size, int64_t K, int64_t D, float decay, float one_minus_decay,
+                             float* ee_out, t5vq_stream_t stream) {
+    return t5vq_ema_embed_fixed_img_f32(ema_w, w, embed_sum, max_xx_bits, cluster_size, K, D, decay, one_minus_decay,
+                                        ee_out, nullptr, stream);
 }
 
 int t5vq_ste_backward_f32(const float* g_out, const float* diff, const float* g_loss, float coef, int64_t n_elems,
@@ -2578,7 +2678,14 @@ int64_t t5vq_rmsnorm_backward_blocks(int64_t N) {
 
 int t5vq_rmsnorm_sqnorms_f32(const float* hidden, const float* gamma, const uint8_t* keep, float scale, float eps,
                              int64_t N, int64_t D, float* x_out, float* xx, float* rms, t5vq_stream_t stream) {
+    return t5vq_rmsnorm_sqnorms_img_f32(hidden, gamma, keep, scale, eps, N, D, x_out, xx, rms, nullptr, stream);
+}
+int t5vq_rmsnorm_sqnorms_img_f32(const float* hidden, const float* gamma, const uint8_t* keep, float scale, float eps,
+                                 int64_t N, int64_t D, float* x_out, float* xx, float* rms, void* token_image,
+                                 t5vq_stream_t stream) {
     T5VQ_REQUIRE(hidden && gamma && x_out, "null pointer");
+    T5VQ_REQUIRE((reinterpret_cast<uintptr_t>(token_image) & 255u) == 0, "token_image must be 256-byte aligned");
+    const T5vqTokenImage timg = t5vq_token_image_parts(token_image, N, D);
     T5VQ_REQUIRE(N > 0 && N < (1LL << 31) && D > 0 && D % 4 == 0, "N, D out of range");
     T5VQ_REQUIRE(aligned16(hidden) && aligned16(gamma) && aligned16(x_out), "16-byte alignment");
     T5VQ_REQUIRE(!keep || (reinterpret_cast<uintptr_t>(keep) & 3u) == 0, "keep mask must be 4-byte aligned");
@@ -2587,7 +2694,7 @@ int t5vq_rmsnorm_sqnorms_f32(const float* hidden, const float* gamma, const uint
     const dim3 grid(static_cast<unsigned>((N + 3) / 4));
 #define T5VQ_RN(NCH_)                                                                                              \
     hipLaunchKernelGGL((rmsnorm_sqnorms_kernel<NCH_>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), hidden, \
-                       gamma, keep, scale, eps, static_cast<int>(N), static_cast<int>(D), x_out, xx, rms)
+                       gamma, keep, scale, eps, static_cast<int>(N), static_cast<int>(D), x_out, xx, rms, timg)
     switch (nch) {
         case 1: T5VQ_RN(1); break;
         case 2: T5VQ_RN(2); break;
@@ -2855,6 +2962,16 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
                                  int64_t workspace_bytes, float* out_ste, float* out_q, float* out_diff,
                                  int64_t* idx_out, float* counts, float* embed_sum, float* loss_terms, float* loss_sum,
                                  int32_t* n_overflow, t5vq_stream_t stream_) {
+    return t5vq_vq_forward_filtered_img_f32(x, w, range, xx_in, ee_in, N, K, D, loss_kind, workspace, workspace_bytes,
+                                            out_ste, out_q, out_diff, idx_out, counts, embed_sum, loss_terms, loss_sum,
+                                            n_overflow, nullptr, 0, nullptr, stream_);
+}
+int t5vq_vq_forward_filtered_img_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
+                                     const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind,
+                                     void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,
+                                     float* out_diff, int64_t* idx_out, float* counts, float* embed_sum,
+                                     float* loss_terms, float* loss_sum, int32_t* n_overflow, void* code_image,
+                                     int code_image_valid, const void* token_image, t5vq_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     T5VQ_REQUIRE(N > 0 && K > 0, "N and K must be positive");
     const FwdWorkspace ws(N, K);
@@ -2893,7 +3010,8 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
         role_order = p;
     }
     int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, role_order, N, K, D, 0, 0,
-                                                base + ws.total, filter_bytes, keys, n_overflow, zero, stream);
+                                                base + ws.total, filter_bytes, keys, n_overflow, zero, code_image,
+                                                code_image_valid, token_image, stream);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
     if (order) {
@@ -2908,17 +3026,27 @@ int t5vq_vq_forward_filtered_f32(const float* x, const float* w, const int64_t* 
     return t5vq_reduce_partials_f32(partial, perm ? N : t5vq_gather_blocks(N), loss_sum, stream);
 }
 
-int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
-                             const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K, int64_t D,
-                             int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
-                             float k_epsilon, float commitment_cost, int plain_variant, int update, float* scalars,
-                             float* ee_out, t5vq_stream_t stream) {
+int t5vq_vq_ema_finalize_img_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
+                                 const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K,
+                                 int64_t D, int64_t n_tokens, float loss_denom, float decay, float one_minus_decay,
+                                 float epsilon, float k_epsilon, float commitment_cost, int plain_variant, int update,
+                                 float* scalars, float* ee_out, void* code_image, t5vq_stream_t stream) {
     T5VQ_REQUIRE(!update || (cluster_size && ema_w && w && embed_sum), "update needs cluster_size, ema_w, w, embed_sum");
     int rc = t5vq_ema_cluster_f32(update ? cluster_size : nullptr, counts, loss_sum, n_loss_terms, K, n_tokens,
                                   loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
                                   plain_variant, update ? 1 : 0, scalars, stream);
     if (rc != T5VQ_OK || !update) return rc;
-    return t5vq_ema_embed_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, ee_out, stream);
+    return t5vq_ema_embed_img_f32(ema_w, w, embed_sum, cluster_size, K, D, decay, one_minus_decay, ee_out, code_image,
+                                  stream);
+}
+int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const float* counts,
+                             const float* embed_sum, const float* loss_sum, int64_t n_loss_terms, int64_t K, int64_t D,
+                             int64_t n_tokens, float loss_denom, float decay, float one_minus_decay, float epsilon,
+                             float k_epsilon, float commitment_cost, int plain_variant, int update, float* scalars,
+                             float* ee_out, t5vq_stream_t stream) {
+    return t5vq_vq_ema_finalize_img_f32(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_loss_terms, K, D, n_tokens,
+                                        loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
+                                        plain_variant, update, scalars, ee_out, nullptr, stream);
 }
 
 }  // extern "C"

@@ -60,8 +60,12 @@ struct Fwd {
     OptTensor diff, q, unsettled;
 };
 
+// code_image / token_image (filtered search only): the fp16 image blocks of include/t5vq.h's last section.  A code image
+// is read when code_image_valid, else written by this call's preparation pass; a token image is always a valid one.
 Fwd forward_impl(const Tensor& x, const Tensor& w, const OptTensor& ranges, const OptTensor& xx, const OptTensor& ee,
-                 int64_t loss_kind, bool filtered, bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss) {
+                 int64_t loss_kind, bool filtered, bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss,
+                 const OptTensor& code_image = OptTensor(), bool code_image_valid = false,
+                 const OptTensor& token_image = OptTensor()) {
     need(x, "x", at::kFloat, 2), need(w, "w", at::kFloat, 2);
     const int64_t N = x.size(0), D = x.size(1), K = w.size(0);
     TORCH_CHECK(w.size(1) == D, "x and w disagree on D");
@@ -73,6 +77,17 @@ Fwd forward_impl(const Tensor& x, const Tensor& w, const OptTensor& ranges, cons
     if (xx.has_value()) TORCH_CHECK(need(*xx, "xx").numel() == N, "xx must hold ", N, " row norms");
     if (ee.has_value()) TORCH_CHECK(need(*ee, "ee").numel() == t5vq_padded_codes(K), "ee must be the padded |e|^2 buffer");
     if (filtered) TORCH_CHECK(D % 64 == 0 && D <= 4096, "the filtered search needs D % 64 == 0, D <= 4096");
+    if (code_image.has_value()) {
+        TORCH_CHECK(need(*code_image, "code_image", at::kByte).numel() >= t5vq_code_image_bytes(K, D),
+                    "code_image smaller than t5vq_code_image_bytes(K, D)");
+        TORCH_CHECK(!code_image_valid || ee.has_value(), "a valid code image comes with the codebook's norms (ee)");
+    }
+    if (token_image.has_value()) {
+        TORCH_CHECK(need(*token_image, "token_image", at::kByte).numel() >= t5vq_token_image_bytes(N, D),
+                    "token_image smaller than t5vq_token_image_bytes(N, D)");
+        TORCH_CHECK(xx.has_value(), "a token image comes with the row norms of x (xx)");
+    }
+    same_device(x, code_image, "code_image"), same_device(x, token_image, "token_image");
     same_device(x, w, "w"), same_device(x, ranges, "ranges"), same_device(x, xx, "xx"), same_device(x, ee, "ee");
     const auto f32 = x.options();
     Fwd r;
@@ -88,11 +103,12 @@ Fwd forward_impl(const Tensor& x, const Tensor& w, const OptTensor& ranges, cons
     void* stream = stream_of(x);
     if (filtered) {
         r.unsettled = at::empty({1}, f32.dtype(at::kInt));
-        ok(t5vq_vq_forward_filtered_f32(x.data_ptr<float>(), w.data_ptr<float>(), ptr<int64_t>(ranges), ptr(xx), ptr(ee), N,
-                                        K, D, static_cast<int>(loss_kind), ws.data_ptr(), ws_bytes,
-                                        r.ste.data_ptr<float>(), ptr(r.q), ptr(r.diff), r.idx.data_ptr<int64_t>(),
-                                        sp + st.counts, want_embed_sum ? sp : nullptr, sp + st.terms,
-                                        reduce_loss ? sp + st.loss_sum : nullptr, r.unsettled->data_ptr<int32_t>(), stream),
+        ok(t5vq_vq_forward_filtered_img_f32(
+               x.data_ptr<float>(), w.data_ptr<float>(), ptr<int64_t>(ranges), ptr(xx), ptr(ee), N, K, D,
+               static_cast<int>(loss_kind), ws.data_ptr(), ws_bytes, r.ste.data_ptr<float>(), ptr(r.q), ptr(r.diff),
+               r.idx.data_ptr<int64_t>(), sp + st.counts, want_embed_sum ? sp : nullptr, sp + st.terms,
+               reduce_loss ? sp + st.loss_sum : nullptr, r.unsettled->data_ptr<int32_t>(), ptr<void>(code_image),
+               code_image_valid ? 1 : 0, ptr<void>(token_image), stream),
            "vq_forward (filtered)");
     } else {
         ok(t5vq_vq_forward_f32(x.data_ptr<float>(), w.data_ptr<float>(), ptr<int64_t>(ranges), ptr(xx), ptr(ee), N, K, D,
@@ -107,8 +123,13 @@ Fwd forward_impl(const Tensor& x, const Tensor& w, const OptTensor& ranges, cons
 Tensor finalize_impl(const OptTensor& cs, const OptTensor& ema_w, const OptTensor& w, const Tensor& stats, int64_t N_local,
                      int64_t K, int64_t D, bool with_embed_sum, bool reduced_loss, int64_t n_tokens, double loss_denom,
                      double decay, double one_minus_decay, double epsilon, double k_epsilon, double commitment_cost,
-                     bool plain_variant, bool update, const OptTensor& ee_out) {
+                     bool plain_variant, bool update, const OptTensor& ee_out,
+                     const OptTensor& code_image = OptTensor()) {
     need(stats, "stats");
+    if (code_image.has_value())
+        TORCH_CHECK(need(*code_image, "code_image", at::kByte).numel() >= t5vq_code_image_bytes(K, D),
+                    "code_image smaller than t5vq_code_image_bytes(K, D)");
+    same_device(stats, code_image, "code_image");
     const StatsLayout st(N_local, K, D, with_embed_sum);
     TORCH_CHECK(stats.numel() == st.total, "stats buffer does not match (N, K, D, with_embed_sum)");
     if (update) {
@@ -123,13 +144,14 @@ Tensor finalize_impl(const OptTensor& cs, const OptTensor& ema_w, const OptTenso
     same_device(stats, ee_out, "ee_out");
     Tensor scalars = at::empty({4}, stats.options());
     const float* sp = stats.data_ptr<float>();
-    ok(t5vq_vq_ema_finalize_f32(update ? ptr(cs) : nullptr, update ? ptr(ema_w) : nullptr, update ? ptr(w) : nullptr,
+    ok(t5vq_vq_ema_finalize_img_f32(update ? ptr(cs) : nullptr, update ? ptr(ema_w) : nullptr, update ? ptr(w) : nullptr,
                                 sp + st.counts, update ? sp : nullptr, reduced_loss ? sp + st.loss_sum : sp + st.terms,
                                 reduced_loss ? 1 : st.n_terms, K, D, n_tokens, static_cast<float>(loss_denom),
                                 static_cast<float>(decay), static_cast<float>(one_minus_decay),
                                 static_cast<float>(epsilon), static_cast<float>(k_epsilon),
                                 static_cast<float>(commitment_cost), plain_variant ? 1 : 0, update ? 1 : 0,
-                                scalars.data_ptr<float>(), update ? ptr(ee_out) : nullptr, stream_of(stats)),
+                                scalars.data_ptr<float>(), update ? ptr(ee_out) : nullptr,
+                                update ? ptr<void>(code_image) : nullptr, stream_of(stats)),
        "vq_finalize");
     return scalars;
 }
@@ -139,9 +161,11 @@ Tensor finalize_impl(const OptTensor& cs, const OptTensor& ema_w, const OptTenso
 // t5vq_vq_forward_filtered_f32).  Returns (ste, idx, diff?, q?, stats, unsettled?).
 std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_forward(
     const Tensor& x, const Tensor& w, const OptTensor& ranges, const OptTensor& xx, const OptTensor& ee, int64_t loss_kind,
-    bool filtered, bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss) {
+    bool filtered, bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss, const OptTensor& code_image,
+    bool code_image_valid, const OptTensor& token_image) {
     const c10::DeviceGuard guard(x.device());
-    Fwd r = forward_impl(x, w, ranges, xx, ee, loss_kind, filtered, want_diff, want_q, want_embed_sum, reduce_loss);
+    Fwd r = forward_impl(x, w, ranges, xx, ee, loss_kind, filtered, want_diff, want_q, want_embed_sum, reduce_loss,
+                         code_image, code_image_valid, token_image);
     return {r.ste, r.idx, r.diff, r.q, r.stats, r.unsettled};
 }
 
@@ -150,10 +174,10 @@ std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_forward(
 Tensor vq_finalize(const OptTensor& cs, const OptTensor& ema_w, const OptTensor& w, const Tensor& stats, int64_t n_local,
                    int64_t K, int64_t D, bool with_embed_sum, bool reduced_loss, int64_t n_tokens, double loss_denom,
                    double decay, double one_minus_decay, double epsilon, double k_epsilon, double commitment_cost,
-                   bool plain_variant, bool update, const OptTensor& ee_out) {
+                   bool plain_variant, bool update, const OptTensor& ee_out, const OptTensor& code_image) {
     const c10::DeviceGuard guard(stats.device());
     return finalize_impl(cs, ema_w, w, stats, n_local, K, D, with_embed_sum, reduced_loss, n_tokens, loss_denom, decay,
-                         one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, update, ee_out);
+                         one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, update, ee_out, code_image);
 }
 
 // vq_step = the whole module call on one GPU: vq_forward then vq_finalize, one dispatcher crossing.
@@ -167,7 +191,8 @@ std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_step(
     const Tensor& x, const Tensor& w, const OptTensor& ranges, const OptTensor& xx, const OptTensor& ee,
     const OptTensor& cs, const OptTensor& ema_w, int64_t loss_kind, bool filtered, bool want_diff, bool want_q,
     double loss_denom, double decay, double one_minus_decay, double epsilon, double k_epsilon, double commitment_cost,
-    bool plain_variant, bool update, const OptTensor& ee_out, const OptTensor& small_state) {
+    bool plain_variant, bool update, const OptTensor& ee_out, const OptTensor& small_state, const OptTensor& code_image,
+    bool code_image_valid, const OptTensor& token_image) {
     const c10::DeviceGuard guard(x.device());
     if (!update && small_state.has_value() && small_state->defined() && !ranges.has_value() && !filtered &&
         loss_kind == T5VQ_LOSS_MSE && x.dim() == 2 && w.dim() == 2 && w.size(0) % 4 == 0 && w.size(0) <= 16384 &&
@@ -194,11 +219,12 @@ std::tuple<Tensor, Tensor, OptTensor, OptTensor, Tensor, OptTensor> vq_step(
            "vq_step (single launch)");
         return {ste, idx, diff, q, scalars, OptTensor()};
     }
-    Fwd r = forward_impl(x, w, ranges, xx, ee, loss_kind, filtered, want_diff, want_q, update, false);
+    Fwd r = forward_impl(x, w, ranges, xx, ee, loss_kind, filtered, want_diff, want_q, update, false, code_image,
+                         code_image_valid, token_image);
     const OptTensor wopt = update ? OptTensor(w) : OptTensor();
     Tensor scalars = finalize_impl(cs, ema_w, wopt, r.stats, x.size(0), w.size(0), x.size(1), update, false, x.size(0),
                                    loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
-                                   update, ee_out);
+                                   update, ee_out, code_image);   // the update leaves the NEW codebook's image there
     return {r.ste, r.idx, r.diff, r.q, scalars, r.unsettled};
 }
 
@@ -304,16 +330,19 @@ void no_cpu_path(const c10::OperatorHandle& op, c10::Stack*) {
 
 TORCH_LIBRARY(t5vq, m) {
     m.def("vq_forward(Tensor x, Tensor w, Tensor? ranges, Tensor? xx, Tensor? ee, int loss_kind, bool filtered, "
-          "bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss) -> "
+          "bool want_diff, bool want_q, bool want_embed_sum, bool reduce_loss, Tensor(f!)? code_image=None, "
+          "bool code_image_valid=False, Tensor? token_image=None) -> "
           "(Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
     m.def("vq_finalize(Tensor(a!)? cluster_size, Tensor(b!)? ema_w, Tensor(c!)? w, Tensor stats, int n_local, int K, int D, "
           "bool with_embed_sum, bool reduced_loss, int n_tokens, float loss_denom, float decay, float one_minus_decay, "
-          "float epsilon, float k_epsilon, float commitment_cost, bool plain_variant, bool update, Tensor(d!)? ee_out) "
+          "float epsilon, float k_epsilon, float commitment_cost, bool plain_variant, bool update, Tensor(d!)? ee_out, "
+          "Tensor(f!)? code_image=None) "
           "-> Tensor");
     m.def("vq_step(Tensor x, Tensor(c!) w, Tensor? ranges, Tensor? xx, Tensor? ee, Tensor(a!)? cluster_size, "
           "Tensor(b!)? ema_w, int loss_kind, bool filtered, bool want_diff, bool want_q, float loss_denom, float decay, "
           "float one_minus_decay, float epsilon, float k_epsilon, float commitment_cost, bool plain_variant, bool update, "
-          "Tensor(d!)? ee_out, Tensor(e!)? small_state) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
+          "Tensor(d!)? ee_out, Tensor(e!)? small_state, Tensor(f!)? code_image=None, bool code_image_valid=False, "
+          "Tensor? token_image=None) -> (Tensor, Tensor, Tensor?, Tensor?, Tensor, Tensor?)");
     m.def("ste_backward(Tensor? g_out, Tensor diff, Tensor? g_loss, float coef) -> Tensor");
     m.def("scatter_rows(Tensor rows, Tensor idx, Tensor? scale_dev, float scale_host, int K) -> Tensor");
     m.def("cosine_backward(Tensor x, Tensor q, Tensor? g_out, Tensor? g_loss, float coef_x, float coef_q, "

@@ -26,19 +26,22 @@ from . import ops
 
 class _TailFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hidden, gamma, keep, scale, eps):
-        x, xx, rms = ops.rmsnorm_sqnorms(hidden, gamma.detach(), keep, scale, eps, want_rms=True)
+    def forward(ctx, hidden, gamma, keep, scale, eps, want_image):
+        ximg = ops.token_image(hidden.shape[0], hidden.shape[1], hidden.device) if want_image else None
+        x, xx, rms = ops.rmsnorm_sqnorms(hidden, gamma.detach(), keep, scale, eps, want_rms=True, token_image=ximg)
         ctx.save_for_backward(hidden, gamma.detach(), keep, rms)
         ctx.scale = scale
-        ctx.mark_non_differentiable(xx)
-        return x, xx
+        if ximg is None:                      # (an autograd Function returns tensors: an empty block stands for "none")
+            ximg = torch.empty(0, dtype=torch.uint8, device=hidden.device)
+        ctx.mark_non_differentiable(xx, ximg)
+        return x, xx, ximg
 
     @staticmethod
-    def backward(ctx, g_x, g_xx):
+    def backward(ctx, g_x, g_xx, g_ximg):
         hidden, gamma, keep, rms = ctx.saved_tensors
         gh, gg = ops.rmsnorm_backward(g_x, hidden, gamma, keep, ctx.scale, rms,
                                       want_grad_gamma=ctx.needs_input_grad[1])
-        return (gh if ctx.needs_input_grad[0] else None), gg, None, None, None
+        return (gh if ctx.needs_input_grad[0] else None), gg, None, None, None, None
 
 
 class EncoderTailVQ(nn.Module):
@@ -67,5 +70,18 @@ class EncoderTailVQ(nn.Module):
         elif self.training and self.dropout_rate > 0.0:
             keep = torch.empty(flat.shape, dtype=torch.uint8, device=flat.device).bernoulli_(1.0 - self.dropout_rate)
             scale = 1.0 / (1.0 - self.dropout_rate)
-        x, xx = _TailFunction.apply(flat, self.weight, keep, scale, float(self.variance_epsilon))
-        return self.vq(x.view(hidden_states.shape), srl, _xx=xx)
+        x, xx, ximg = _TailFunction.apply(flat, self.weight, keep, scale, float(self.variance_epsilon),
+                                          self._wants_image(flat.shape[0], d, srl))
+        return self.vq(x.view(hidden_states.shape), srl, _xx=xx, _ximg=ximg if ximg.numel() else None)
+
+    def _wants_image(self, n: int, d: int, srl) -> bool:
+        """Whether the quantizer's search of this call will be the filtered one in token order -- then the norm kernel
+        also writes the fp16 image of its output and the search's preparation pass does not read x again.  (A wrong
+        guess costs one unused write of N * D * 2 bytes, or the usual preparation pass: never a result.)"""
+        vq = self.vq
+        search = getattr(vq, "search", "scan")
+        if search == "scan" or d % 64 or d > 2048:
+            return False
+        if srl is not None and getattr(vq, "disentanglement", False) and n >= 1024:
+            return False                       # role order: the search lays its image out in that order itself
+        return search == "filter" or n * vq._num_embeddings >= vq.filter_min_work

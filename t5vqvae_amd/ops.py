@@ -131,13 +131,16 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
 
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True,
-                         ranges=None, code_offset: int = 0, return_norms: bool = False, order=None):
+                         ranges=None, code_offset: int = 0, return_norms: bool = False, order=None,
+                         code_image=None, code_image_valid: bool = False, token_image=None):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
     (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None (either or both): that norm is computed by the call's own
     first pass (no separate ``row_sqnorms``); a given norm is only read.  ``exact_keys=False``: only the index word is
     guaranteed (cheaper).  ``order`` (ranged search only): the visiting order of the tokens (``order_by_range``).
     Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``; ``return_norms`` appends (xx, ee) -- the
-    norms the search used, whether given or computed."""
+    norms the search used, whether given or computed.  ``code_image`` (a ``code_image()`` block): the codebook's fp16
+    image is read from it when ``code_image_valid`` (``ee`` must be given), else this call writes it there;
+    ``token_image``: a valid image of x from its producer (``xx`` must be given; ignored with ``order``)."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
@@ -169,14 +172,36 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
     nbytes = int(lib.t5vq_filter_workspace_bytes(n, k, d))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     ovf = torch.empty(1, dtype=torch.int32, device=x.device) if want_overflow else None
+    _check_images(lib, code_image, token_image, n, k, d)
     with torch.cuda.device(x.device):
-        _lib.check(lib.t5vq_dist_argmin_filtered_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges), _p(order),
-                                                     n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
-                                                     _p(keys), _p(ovf), _stream(x)), "dist_argmin_filtered")
+        _lib.check(lib.t5vq_dist_argmin_filtered_img_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges), _p(order),
+                                                         n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
+                                                         _p(keys), _p(ovf), _p(code_image),
+                                                         1 if code_image_valid else 0, _p(token_image), _stream(x)),
+                   "dist_argmin_filtered")
     out = (keys, ovf) if want_overflow else (keys,)
     if return_norms:
         out = out + (xx, ee)
     return out if len(out) > 1 else keys
+
+
+def code_image(k: int, d: int, device) -> torch.Tensor:
+    """An (uninitialised) block for the fp16 image of a [k, d] codebook (t5vq_code_image_bytes): filled by a filtered
+    search called with ``code_image_valid=False`` or by the codebook update, read by later searches."""
+    return torch.empty(int(_lib.load().t5vq_code_image_bytes(k, d)), dtype=torch.uint8, device=device)
+
+
+def token_image(n: int, d: int, device) -> torch.Tensor:
+    """An (uninitialised) block for the fp16 image of [n, d] inputs (t5vq_token_image_bytes), filled by
+    ``rmsnorm_sqnorms(..., token_image=...)``."""
+    return torch.empty(int(_lib.load().t5vq_token_image_bytes(n, d)), dtype=torch.uint8, device=device)
+
+
+def _check_images(lib, code_img, token_img, n: int, k: int, d: int):
+    if code_img is not None and _need(code_img, "code_image", torch.uint8).numel() < int(lib.t5vq_code_image_bytes(k, d)):
+        raise RuntimeError("code_image smaller than t5vq_code_image_bytes(K, D)")
+    if token_img is not None and _need(token_img, "token_image", torch.uint8).numel() < int(lib.t5vq_token_image_bytes(n, d)):
+        raise RuntimeError("token_image smaller than t5vq_token_image_bytes(N, D)")
 
 
 def unpack_keys(keys, want_idx=True, want_dmin=False):
@@ -396,7 +421,7 @@ def vq_forward_small(x, w, state, *, xx=None, ee=None, ste=None, q=None, diff=No
 
 def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: int, loss_denom: float, decay: float,
                  one_minus_decay: float, epsilon: float, k_epsilon: float, commitment_cost: float,
-                 plain_variant: bool, update: bool, scalars, ee_out=None):
+                 plain_variant: bool, update: bool, scalars, ee_out=None, code_image=None):
     """EMA update (if ``update``) + loss / perplexity scalars behind one host call (t5vq_vq_ema_finalize_f32, ctypes
     route).  ``loss_sum``: one ready sum, or the forward's unreduced loss terms (all its elements are added up)."""
     lib = _lib.load()
@@ -411,13 +436,16 @@ def ema_finalize(cluster_size, ema_w, w, counts, embed_sum, loss_sum, n_tokens: 
             raise RuntimeError("ema_finalize: inconsistent shapes")
     if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
         raise RuntimeError("ee_out must hold at least K norms")
+    if update:
+        _check_images(lib, code_image, None, 0, k, d)
     with torch.cuda.device(scalars.device):
-        _lib.check(lib.t5vq_vq_ema_finalize_f32(_p(cluster_size) if update else None, _p(ema_w) if update else None,
+        _lib.check(lib.t5vq_vq_ema_finalize_img_f32(_p(cluster_size) if update else None, _p(ema_w) if update else None,
                                                 _p(w) if update else None, _p(counts),
                                                 _p(embed_sum) if update else None, _p(loss_sum), loss_sum.numel(), k, d,
                                                 n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
                                                 commitment_cost, 1 if plain_variant else 0, 1 if update else 0,
-                                                _p(scalars), _p(ee_out) if update else None, _stream(scalars)),
+                                                _p(scalars), _p(ee_out) if update else None,
+                                                _p(code_image) if update else None, _stream(scalars)),
                    "ema_finalize")
 
 
@@ -438,36 +466,40 @@ def code_sqnorms(w):
 
 
 def fused_forward(x, w, ranges, loss: str, *, xx=None, ee=None, filtered=False, want_diff=False, want_q=False,
-                  want_embed_sum=False, reduce_loss=False):
-    """(ste, idx, diff | None, q | None, stats, unsettled | None): t5vq::vq_forward."""
+                  want_embed_sum=False, reduce_loss=False, code_image=None, code_image_valid=False, token_image=None):
+    """(ste, idx, diff | None, q | None, stats, unsettled | None): t5vq::vq_forward.  Image blocks: filtered search only
+    (see ``dist_argmin_filtered``)."""
     return _lib.load_torch_ops().vq_forward(x, w, ranges, xx, ee, LOSS_KINDS[loss], filtered, want_diff, want_q,
-                                            want_embed_sum, reduce_loss)
+                                            want_embed_sum, reduce_loss, code_image, code_image_valid, token_image)
 
 
 def fused_finalize(cluster_size, ema_w, w, stats, n_local: int, k: int, d: int, with_embed_sum: bool,
                    reduced_loss: bool, n_tokens: int, loss_denom: float, decay: float, one_minus_decay: float,
                    epsilon: float, k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool,
-                   ee_out=None):
-    """scalars [loss, perplexity, n, raw latent loss]: t5vq::vq_finalize."""
+                   ee_out=None, code_image=None):
+    """scalars [loss, perplexity, n, raw latent loss]: t5vq::vq_finalize.  ``code_image``: with ``update`` the fp16 image
+    of the codebook just written goes there."""
     return _lib.load_torch_ops().vq_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum, reduced_loss,
                                              n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
-                                             commitment_cost, plain_variant, update, ee_out)
+                                             commitment_cost, plain_variant, update, ee_out, code_image)
 
 
 def fused_step(x, w, ranges, loss: str, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False,
                want_diff=False, want_q=False, loss_denom: float, decay: float, one_minus_decay: float, epsilon: float,
                k_epsilon: float, commitment_cost: float, plain_variant: bool, update: bool, ee_out=None,
-               small_state=None):
+               small_state=None, code_image=None, code_image_valid=False, token_image=None):
     """(ste, idx, diff | None, q | None, scalars, unsettled | None): the whole module call on one GPU behind one op
     (t5vq::vq_step = vq_forward + vq_finalize); scalars = [loss, perplexity, n, raw latent loss].  ``small_state`` (a
     block from ``small_state()``): calls without an EMA update on small problems then take ONE launch."""
     return _lib.load_torch_ops().vq_step(x, w, ranges, xx, ee, cluster_size, ema_w, LOSS_KINDS[loss], filtered,
                                          want_diff, want_q, loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
-                                         commitment_cost, plain_variant, update, ee_out, small_state)
+                                         commitment_cost, plain_variant, update, ee_out, small_state, code_image,
+                                         code_image_valid, token_image)
 
 
-def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: bool = True):
-    """(x, xx, rms): T5LayerNorm + dropout mask + row norms of the result in one pass (t5vq_rmsnorm_sqnorms_f32)."""
+def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: bool = True, token_image=None):
+    """(x, xx, rms): T5LayerNorm + dropout mask + row norms of the result in one pass (t5vq_rmsnorm_sqnorms_f32).
+    ``token_image`` (a ``token_image()`` block): the same pass writes the fp16 image of x the filtered search takes."""
     lib = _lib.load()
     _need(hidden, "hidden", ndim=2), _need(gamma, "gamma", ndim=1)
     n, d = hidden.shape
@@ -480,9 +512,10 @@ def rmsnorm_sqnorms(hidden, gamma, keep, scale: float, eps: float, want_rms: boo
     x = torch.empty_like(hidden)
     xx = torch.empty(n, dtype=torch.float32, device=hidden.device)
     rms = torch.empty(n, dtype=torch.float32, device=hidden.device) if want_rms else None
+    _check_images(lib, None, token_image, n, 1, d)
     with torch.cuda.device(hidden.device):
-        _lib.check(lib.t5vq_rmsnorm_sqnorms_f32(_p(hidden), _p(gamma), _p(keep), scale, eps, n, d, _p(x), _p(xx),
-                                                _p(rms), _stream(hidden)), "rmsnorm_sqnorms")
+        _lib.check(lib.t5vq_rmsnorm_sqnorms_img_f32(_p(hidden), _p(gamma), _p(keep), scale, eps, n, d, _p(x), _p(xx),
+                                                    _p(rms), _p(token_image), _stream(hidden)), "rmsnorm_sqnorms")
     return x, xx, rms
 
 
@@ -525,15 +558,16 @@ def ema_cluster(cluster_size, counts, loss_sum, k: int, n_tokens: int, loss_deno
                    "ema_cluster")
 
 
-def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: float, ee_out=None):
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay: float, one_minus_decay: float, ee_out=None, code_image=None):
     lib = _lib.load()
     _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum, "embed_sum"), _need(cluster_size, "cs")
     k, d = ema_w.shape
     if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
         raise RuntimeError("ee_out must hold at least K norms")
+    _check_images(lib, code_image, None, 0, k, d)
     with torch.cuda.device(w.device):
-        _lib.check(lib.t5vq_ema_embed_f32(_p(ema_w), _p(w), _p(embed_sum), _p(cluster_size), k, d, decay,
-                                          one_minus_decay, _p(ee_out), _stream(w)), "ema_embed")
+        _lib.check(lib.t5vq_ema_embed_img_f32(_p(ema_w), _p(w), _p(embed_sum), _p(cluster_size), k, d, decay,
+                                              one_minus_decay, _p(ee_out), _p(code_image), _stream(w)), "ema_embed")
 
 
 def max_norm(xx):
@@ -561,7 +595,7 @@ def embed_sum_fixed(x, keys, max_bits, k: int, stats_begin: int = 0, stats_count
 
 
 def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay: float, one_minus_decay: float,
-                    ee_out=None):
+                    ee_out=None, code_image=None):
     lib = _lib.load()
     _need(ema_w, "ema_w", ndim=2), _need(w, "w", ndim=2), _need(embed_sum_i64, "embed_sum", torch.int64)
     _need(max_bits, "max_bits", torch.int32), _need(cluster_size, "cs")
@@ -570,9 +604,11 @@ def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay: floa
         raise RuntimeError("ema_embed_fixed: embed_sum must be [K, D]")
     if ee_out is not None and _need(ee_out, "ee_out").numel() < k:
         raise RuntimeError("ee_out must hold at least K norms")
+    _check_images(lib, code_image, None, 0, k, d)
     with torch.cuda.device(w.device):
-        _lib.check(lib.t5vq_ema_embed_fixed_f32(_p(ema_w), _p(w), _p(embed_sum_i64), _p(max_bits), _p(cluster_size), k,
-                                                d, decay, one_minus_decay, _p(ee_out), _stream(w)), "ema_embed_fixed")
+        _lib.check(lib.t5vq_ema_embed_fixed_img_f32(_p(ema_w), _p(w), _p(embed_sum_i64), _p(max_bits), _p(cluster_size),
+                                                    k, d, decay, one_minus_decay, _p(ee_out), _p(code_image),
+                                                    _stream(w)), "ema_embed_fixed")
 
 
 def ste_backward(g_out, diff, g_loss, coef: float):

@@ -50,6 +50,13 @@ def _filter_state(module):
 _EE_STATE = weakref.WeakKeyDictionary()
 
 
+# fp16 image of the codebook for the filtered search (ops.code_image), kept between calls like |e|^2 and under the same
+# key: (block, data_ptr, _version).  The kernel that writes the codebook (EMA update) writes its image too, a search that
+# finds no valid image makes it in the module's block instead of its own workspace -- either way the NEXT search's
+# preparation pass reads no codebook row.  Only the base module's own flows keep one.
+_IMG_STATE = weakref.WeakKeyDictionary()
+
+
 # State block of the single-launch small-shape forward (tickets; zeroed once, left zeroed by every launch), one per
 # module and device: calls of one module are ordered, calls of different modules may overlap.
 _SMALL_STATE = weakref.WeakKeyDictionary()
@@ -58,7 +65,7 @@ _SMALL_STATE = weakref.WeakKeyDictionary()
 class _Plan:
     """Per-call configuration handed to the autograd function (plain Python, no tensors)."""
     __slots__ = ("ema", "training", "cc", "decay", "eps", "loss", "batch", "group", "world_tokens", "module", "xx",
-                 "grad_scale")
+                 "grad_scale", "ximg")
 
 
 def _scalar_of(buf: torch.Tensor, i: int) -> torch.Tensor:
@@ -175,7 +182,7 @@ class _QuantizerBase(nn.Module):
     index_mode = "reference"     # disentangled mode: "reference" = slice-relative indices used as rows (the
     #                              reference's behaviour, vqvae/vqvae.py:116-119) | "absolute" = start + argmin
 
-    def _nearest_keys(self, x, w, ranges, code_offset=0, xx=None, exact_keys=True, use_filter=None):
+    def _nearest_keys(self, x, w, ranges, code_offset=0, xx=None, exact_keys=True, use_filter=None, images=None):
         """Packed (distance, index) keys of the nearest admissible codeword per token.
 
         Disentangled mode with many tokens: the search visits the tokens role by role (``ops.order_by_range``: a
@@ -193,7 +200,7 @@ class _QuantizerBase(nn.Module):
         if use_filter:
             # norms that are not given are written by the search's own first pass (bit-identical to row_sqnorms)
             return self._filtered_keys(x, w, exact_keys or code_offset != 0, ranges, code_offset, xx=xx, ee=ee,
-                                       order=order)
+                                       order=order, images=images)
         if xx is None or ee is None:
             xx_, ee_ = ops.row_sqnorms(x if xx is None else None, w if ee is None else None)
             xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
@@ -206,6 +213,41 @@ class _QuantizerBase(nn.Module):
         """Drop the cached |e|^2 (needed only after an in-place write through ``_embedding.weight.data``, which the
         Parameter's version counter does not see)."""
         _EE_STATE.pop(self, None)
+        _IMG_STATE.pop(self, None)
+
+    code_image_cache = True      # False: every filtered search makes the codebook's fp16 image itself, in its workspace
+
+    def _images(self, w, ee, use_filter, update, ximg):
+        """Keyword arguments about fp16 images for this call's ops: ``code_image`` / ``code_image_valid`` for the search
+        (and, with ``update``, the block the new codebook's image goes to), ``token_image`` from the producer of x."""
+        out = {}
+        if ximg is not None and use_filter:
+            out["token_image"] = ximg
+        param = self._embedding.weight
+        if not self.code_image_cache or ee is None or w.data_ptr() != param.data_ptr() or w.shape[1] % 64:
+            return out
+        ent = _IMG_STATE.get(self)
+        if ent is not None and (ent[0].device != w.device or ent[3] != tuple(w.shape)):
+            ent = None
+        if ent is None:
+            if not use_filter:
+                return out                                   # nobody has asked for an image yet
+            ent = (ops.code_image(w.shape[0], w.shape[1], w.device), None, None, tuple(w.shape))
+        valid = ent[1] == param.data_ptr() and ent[2] == param._version
+        if use_filter or update:
+            out["code_image"] = ent[0]
+            out["code_image_valid"] = bool(valid and use_filter)
+            _IMG_STATE[self] = (ent[0], None, None, ent[3])     # in the making: _image_done() stamps it
+        return out
+
+    def _image_done(self, images):
+        """After the call's last op: the block holds the image of the codebook as the call leaves it (made by the
+        search's first pass, or by the update) -- stamp it with the Parameter's pointer and version as they are NOW."""
+        if "code_image" in images:
+            param = self._embedding.weight
+            ent = _IMG_STATE.get(self)
+            if ent is not None and ent[0] is images["code_image"]:
+                _IMG_STATE[self] = (ent[0], param.data_ptr(), param._version, ent[3])
 
     def _code_norms(self, w, make=False):
         """The cached padded |e|^2 of ``w`` (this module's codebook tensor) if still valid, else None -- or, with
@@ -249,9 +291,9 @@ class _QuantizerBase(nn.Module):
             return False
         return True
 
-    def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0, xx=None, ee=None, order=None):
+    def _filtered_keys(self, x, w, exact_keys, ranges=None, code_offset=0, xx=None, ee=None, order=None, images=None):
         keys, ovf = ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, want_overflow=True, exact_keys=exact_keys,
-                                             ranges=ranges, code_offset=code_offset, order=order)
+                                             ranges=ranges, code_offset=code_offset, order=order, **(images or {}))
         self._note_unsettled(ovf, x.shape[0])
         return keys
 
@@ -314,6 +356,9 @@ class _QuantizerBase(nn.Module):
         cs = self._ema_cluster_size if update else None
         ema_w = self._ema_w.data if update else None
         dims = (n_total, d, k, batch)
+        images = self._images(w, ee, use_filter, update, plan.ximg)
+        search_images = {key: v for key, v in images.items() if use_filter}
+        code_image_out = images.get("code_image") if update else None
 
         if not bucketed and not fixed and plan.group is None:        # the whole call behind one op
             small = None
@@ -327,7 +372,8 @@ class _QuantizerBase(nn.Module):
             ste, idx, diff, q, scalars, ovf = ops.fused_step(
                 x, w, ranges, plan.loss, xx=plan.xx, ee=ee, cluster_size=cs, ema_w=ema_w, filtered=use_filter,
                 want_diff=want_diff, want_q=want_q, loss_denom=denom, update=update, ee_out=ee if update else None,
-                small_state=small, **hyper)
+                small_state=small, **images, **hyper)
+            self._image_done(images)
             if ovf is not None:
                 self._note_unsettled(ovf, n)
             self._last_scalars = scalars
@@ -341,7 +387,7 @@ class _QuantizerBase(nn.Module):
         if not bucketed and not overlap:
             ste, idx, diff, q, stats, ovf = ops.fused_forward(
                 x, w, ranges, plan.loss, xx=plan.xx, ee=ee, filtered=use_filter, want_diff=want_diff, want_q=want_q,
-                want_embed_sum=with_es, reduce_loss=reduce_loss)
+                want_embed_sum=with_es, reduce_loss=reduce_loss, **search_images)
             if ovf is not None:
                 self._note_unsettled(ovf, n)
         else:
@@ -352,7 +398,7 @@ class _QuantizerBase(nn.Module):
             diff = torch.empty_like(x) if want_diff else None
             q = torch.empty_like(x) if want_q else None
             keys = self._absolute(self._nearest_keys(x, w, ranges, xx=plan.xx, exact_keys=False,
-                                                     use_filter=use_filter), ranges)
+                                                     use_filter=use_filter, images=search_images), ranges)
             # embed_sum wanted and enough tokens: walk them grouped by code (one flush per run of equal codes)
             perm = ops.order_by_code(keys, k) if (with_es and n >= ops.ORDER_MIN_TOKENS) else None
             out = dict(ste=ste, q=q, diff=diff, idx=idx)
@@ -392,21 +438,26 @@ class _QuantizerBase(nn.Module):
             ops.ema_cluster(self._ema_cluster_size, stats[counts_off:counts_off + k], loss_in, k, n_total, denom,
                             plan.decay, 1 - plan.decay, plan.eps, k * plan.eps, plan.cc, not plan.ema, 1, scalars)
             ops.ema_embed_fixed(self._ema_w.data, self._embedding.weight.data, esum, max_bits,
-                                self._ema_cluster_size, plan.decay, 1 - plan.decay, ee_out=ee)
+                                self._ema_cluster_size, plan.decay, 1 - plan.decay, ee_out=ee,
+                                code_image=code_image_out)
         else:
             scalars = ops.fused_finalize(cs, ema_w, w if update else None, stats, n, k, d, with_es, reduce_loss,
-                                         n_total, denom, update=update, ee_out=ee if update else None, **hyper)
+                                         n_total, denom, update=update, ee_out=ee if update else None,
+                                         code_image=code_image_out, **hyper)
+        self._image_done(images)
         self._last_scalars = scalars
         return {"loss": _scalar_of(scalars, 0), "ppl": _scalar_of(scalars, 1), "ste": ste, "idx": idx, "diff": diff,
                 "q": q, "dims": dims}
 
-    def forward(self, inputs, srl=None, _xx=None):
+    def forward(self, inputs, srl=None, _xx=None, _ximg=None):
         """``_xx`` (not part of the reference interface): |x_i|^2 [N] if the producer of ``inputs`` already has them
-        (t5vqvae_amd.encoder_tail); they must be the row norms of exactly this tensor."""
+        (t5vqvae_amd.encoder_tail); they must be the row norms of exactly this tensor.  ``_ximg``: its fp16 image block
+        (``ops.token_image``) from the same producer, for the filtered search (needs ``_xx``)."""
         self._check_loss_name()
         flat, ranges = self._flatten(inputs, srl)
         plan = _Plan()
         plan.xx = _xx
+        plan.ximg = _ximg if _xx is not None else None
         plan.ema, plan.training = self._is_ema, self.training
         plan.cc = float(self._commitment_cost)
         plan.decay = float(getattr(self, "_decay", 0.0))

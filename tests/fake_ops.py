@@ -79,8 +79,32 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset=0, keys=None, merge=False
     return keys
 
 
+# fp16 image blocks, as the host logic sees them: a block that holds a COPY of the rows it stands for.  A search told that
+# its code image is valid searches THE IMAGE, so a stale or never-written image changes results and a test notices.
+def code_image(k, d, device=None):
+    return torch.full((k * d,), float("nan"))
+
+
+def token_image(n, d, device=None):
+    return torch.full((n * d,), float("nan"))
+
+
+def _through_images(x, w, code_image, code_image_valid, token_image):
+    if code_image is not None:
+        if code_image_valid:
+            w = code_image.view(w.shape).clone()
+        else:
+            code_image.copy_(w.reshape(-1))
+    if token_image is not None:
+        x = token_image.view(x.shape).clone()
+    return x, w
+
+
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True, ranges=None,
-                         code_offset=0, order=None):
+                         code_offset=0, order=None, code_image=None, code_image_valid=False, token_image=None):
+    assert not code_image_valid or ee is not None
+    assert token_image is None or xx is not None
+    x, w = _through_images(x, w, code_image, code_image_valid, None if order is not None else token_image)
     xx_, ee_ = row_sqnorms(x, w)
     xx, ee = (xx_ if xx is None else xx), (ee_ if ee is None else ee)
     out = dist_argmin(x, w, xx, ee, ranges, code_offset=code_offset, keys=keys, order=order)
@@ -191,7 +215,13 @@ def code_sqnorms(w):
 
 
 def fused_forward(x, w, ranges, loss, *, xx=None, ee=None, filtered=False, want_diff=False, want_q=False,
-                  want_embed_sum=False, reduce_loss=False):
+                  want_embed_sum=False, reduce_loss=False, code_image=None, code_image_valid=False, token_image=None):
+    if filtered:
+        assert not code_image_valid or ee is not None
+        assert token_image is None or xx is not None
+        x, w = _through_images(x, w, code_image, code_image_valid, token_image)
+    else:
+        assert not code_image_valid and token_image is None
     n, d = x.shape
     k = w.shape[0]
     kd, counts_off, loss_off, terms_off, n_terms = stats_layout(n, k, d, want_embed_sum)
@@ -207,7 +237,8 @@ def fused_forward(x, w, ranges, loss, *, xx=None, ee=None, filtered=False, want_
 
 
 def fused_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum, reduced_loss, n_tokens, loss_denom,
-                   decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, update, ee_out=None):
+                   decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant, update, ee_out=None,
+                   code_image=None):
     kd, counts_off, loss_off, terms_off, n_terms = stats_layout(n_local, k, d, with_embed_sum)
     assert stats.numel() == terms_off + n_terms
     scalars = torch.empty(4)
@@ -215,25 +246,31 @@ def fused_finalize(cluster_size, ema_w, w, stats, n_local, k, d, with_embed_sum,
     ema_finalize(cluster_size, ema_w, w, stats[counts_off:counts_off + k], stats[:kd].view(k, d) if kd else None,
                  loss_in, n_tokens, loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost,
                  plain_variant, update, scalars, ee_out)
+    if update and code_image is not None:
+        code_image.copy_(w.reshape(-1))
     return scalars
 
 
 def fused_step(x, w, ranges, loss, *, xx=None, ee=None, cluster_size=None, ema_w=None, filtered=False, want_diff=False,
                want_q=False, loss_denom, decay, one_minus_decay, epsilon, k_epsilon, commitment_cost, plain_variant,
-               update, ee_out=None, small_state=None):
+               update, ee_out=None, small_state=None, code_image=None, code_image_valid=False, token_image=None):
     ste, idx, diff, q, stats, ovf = fused_forward(x, w, ranges, loss, xx=xx, ee=ee, filtered=filtered,
-                                                  want_diff=want_diff, want_q=want_q, want_embed_sum=update)
+                                                  want_diff=want_diff, want_q=want_q, want_embed_sum=update,
+                                                  code_image=code_image if filtered else None,
+                                                  code_image_valid=code_image_valid, token_image=token_image)
     scalars = fused_finalize(cluster_size, ema_w, w if update else None, stats, x.shape[0], w.shape[0], x.shape[1],
                              update, False, x.shape[0], loss_denom, decay, one_minus_decay, epsilon, k_epsilon,
-                             commitment_cost, plain_variant, update, ee_out)
+                             commitment_cost, plain_variant, update, ee_out, code_image)
     return ste, idx, diff, q, scalars, ovf
 
 
-def rmsnorm_sqnorms(hidden, gamma, keep, scale, eps, want_rms=True):
+def rmsnorm_sqnorms(hidden, gamma, keep, scale, eps, want_rms=True, token_image=None):
     r = torch.sqrt((hidden * hidden).mean(-1, keepdim=True) + eps)
     x = gamma * (hidden / r)
     if keep is not None:
         x = torch.where(keep.bool(), x * torch.tensor(scale, dtype=torch.float32), torch.zeros_like(x))
+    if token_image is not None:
+        token_image.copy_(x.reshape(-1))
     return x, (x * x).sum(1), (r.squeeze(1) if want_rms else None)
 
 
@@ -273,12 +310,14 @@ def ema_cluster(cluster_size, counts, loss_sum, k, n_tokens, loss_denom, decay, 
     scalars[3] = m
 
 
-def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay, ee_out=None):
+def ema_embed(ema_w, w, embed_sum, cluster_size, decay, one_minus_decay, ee_out=None, code_image=None):
     f = lambda v: torch.tensor(v, dtype=torch.float32)
     ema_w.copy_(ema_w * f(decay) + f(one_minus_decay) * embed_sum)
     w.copy_(ema_w / cluster_size.unsqueeze(1))
     if ee_out is not None:
         ee_out[:w.shape[0]] = (w * w).sum(1)
+    if code_image is not None:
+        code_image.copy_(w.reshape(-1))
 
 
 def _fixed_shift(max_bits):
@@ -299,9 +338,10 @@ def embed_sum_fixed(x, keys, max_bits, k, stats_begin=0, stats_count=None):
     return torch.zeros(stats_count, x.shape[1], dtype=torch.int64).index_add_(0, i[inside], q[inside])
 
 
-def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay, one_minus_decay, ee_out=None):
+def ema_embed_fixed(ema_w, w, embed_sum_i64, max_bits, cluster_size, decay, one_minus_decay, ee_out=None,
+                    code_image=None):
     dw = (embed_sum_i64.double() * 2.0 ** -_fixed_shift(max_bits)).float()
-    ema_embed(ema_w, w, dw, cluster_size, decay, one_minus_decay, ee_out)
+    ema_embed(ema_w, w, dw, cluster_size, decay, one_minus_decay, ee_out, code_image)
 
 
 def ste_backward(g_out, diff, g_loss, coef):

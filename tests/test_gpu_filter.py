@@ -340,3 +340,156 @@ def test_filtered_keys_identical_to_scan_on_random_shapes():
             if not torch.equal(scan, filt):
                 bad.append((rep, n, k, d, ranged, regime, int((scan != filt).sum())))
     assert not bad, bad
+
+
+def _image_reference(rows):
+    """fp16 image of fp32 rows by the rule of csrc/t5vq_internal.h, in plain torch: every row scaled by the power of two
+    that puts its largest magnitude into [2^14, 2^15) (no scaling for an all-zero row), rounded to nearest even."""
+    m = rows.abs().amax(1)
+    _, ex = torch.frexp(m)                                   # m = mant * 2^ex, mant in [0.5, 1): floor(log2 m) = ex - 1
+    sexp = torch.where(m > 0, 15 - ex, torch.zeros_like(ex)).clamp(-100, 100)
+    img = (rows * torch.pow(2.0, sexp.float()).unsqueeze(1)).to(torch.float16)
+    return img, torch.pow(2.0, -sexp.float())
+
+
+def _code_image_parts(block, k, d):
+    a256 = lambda v: (v + 255) // 256 * 256
+    kpad = (k + 127) // 128 * 128
+    o1 = a256(2 * k * d)
+    o2 = o1 + a256(4 * kpad)
+    return (block[:2 * k * d].view(torch.float16).view(k, d), block[o1:o1 + 4 * kpad].view(torch.float32),
+            block[o2:o2 + 4 * kpad].view(torch.float32))
+
+
+@pytest.mark.parametrize("n,k,d", [(4096, 1000, 768), (300, 130, 64), (65536, 8192, 768)])
+def test_images_from_the_producers_are_the_search_s_own(n, k, d):
+    """The fp16 images written by the codebook update (t5vq_ema_embed_img_f32, the fixed-point form too), by a search
+    asked to fill a block, and by the fused encoder tail (t5vq_rmsnorm_sqnorms_img_f32) are bit-identical to each other
+    and to the rule restated in torch; searches that read them return the keys of a search that makes its own."""
+    from t5vqvae_amd import ops
+    dev = "cuda"
+    torch.manual_seed(n + k)
+    w0 = synth.normal((k, d), 11, 0, device=dev)
+    w0[3] *= 1e6                                             # a dead code's magnitude
+    w0[5] = 0.0                                              # an all-zero row
+    x, _ = synth.clustered(n, w0, 0.6, 12)
+    cs = torch.rand(k, device=dev) + 0.5
+    es = synth.normal((k, d), 13, 0, device=dev)
+    kpad = (k + 127) // 128 * 128
+
+    # (1) the update emits the image of the codebook it writes
+    ema_w, w = (w0 * cs.unsqueeze(1)).clone(), w0.clone()
+    ee = torch.full((kpad,), float("inf"), device=dev)
+    img_u = ops.code_image(k, d, dev)
+    ops.ema_embed(ema_w, w, es, cs, 0.9, 0.1, ee_out=ee, code_image=img_u)
+    ema2, w2 = (w0 * cs.unsqueeze(1)).clone(), w0.clone()
+    ops.ema_embed(ema2, w2, es, cs, 0.9, 0.1)
+    assert torch.equal(w, w2) and torch.equal(ema_w, ema2)   # the codebook itself is untouched by the extra output
+    rows, inv, se = _code_image_parts(img_u, k, d)
+    ref_rows, ref_inv = _image_reference(w)
+    assert torch.equal(rows, ref_rows) and torch.equal(inv[:k], ref_inv)
+    assert torch.equal(se[:k], ee[:k].sqrt()) and bool(torch.isinf(se[k:]).all()) and bool((inv[k:] == 1).all())
+
+    # (2) a search told to fill a block leaves the same bytes there; keys do not depend on where the image came from
+    xx = ops.row_sqnorms(x, None)[0]
+    base = ops.dist_argmin_filtered(x, w, xx, ee)
+    img_f = ops.code_image(k, d, dev)
+    k_fill = ops.dist_argmin_filtered(x, w, xx, ee, code_image=img_f, code_image_valid=False)
+    for a, b in zip(_code_image_parts(img_f, k, d), _code_image_parts(img_u, k, d)):
+        assert torch.equal(a, b)
+    k_read = ops.dist_argmin_filtered(x, w, xx, ee, code_image=img_u, code_image_valid=True)
+    k_scan = ops.dist_argmin(x, w, xx, ee)
+    assert torch.equal(base, k_scan) and torch.equal(k_fill, k_scan) and torch.equal(k_read, k_scan)
+    with pytest.raises(RuntimeError):
+        ops.dist_argmin_filtered(x, w, xx, None, code_image=img_u, code_image_valid=True)   # a valid image needs ee
+
+    # (3) the fixed-point update emits it too
+    mb = ops.max_norm(xx)
+    esum = ops.embed_sum_fixed(x, k_scan, mb, k)
+    ema3, w3, img3 = (w0 * cs.unsqueeze(1)).clone(), w0.clone(), ops.code_image(k, d, dev)
+    ee3 = torch.full((kpad,), float("inf"), device=dev)
+    ops.ema_embed_fixed(ema3, w3, esum, mb, cs, 0.9, 0.1, ee_out=ee3, code_image=img3)
+    r3, i3, s3 = _code_image_parts(img3, k, d)
+    ref3, refi3 = _image_reference(w3)
+    assert torch.equal(r3, ref3) and torch.equal(i3[:k], refi3) and torch.equal(s3[:k], ee3[:k].sqrt())
+
+    # (4) the encoder tail emits the image of the x it produces; the search that reads it returns the same keys
+    if d <= 2048:
+        h = synth.normal((n, d), 14, 0, device=dev)
+        gamma = torch.rand(d, device=dev) + 0.5
+        keep = (torch.rand(n, d, device=dev) > 0.1).to(torch.uint8)
+        timg = ops.token_image(n, d, dev)
+        xt, xxt, _ = ops.rmsnorm_sqnorms(h, gamma, keep, 1 / 0.9, 1e-6, token_image=timg)
+        xt2, xxt2, _ = ops.rmsnorm_sqnorms(h, gamma, keep, 1 / 0.9, 1e-6)
+        assert torch.equal(xt, xt2) and torch.equal(xxt, xxt2)
+        tr, ti = _image_reference(xt)
+        off = (2 * n * d + 255) // 256 * 256
+        assert torch.equal(timg[:2 * n * d].view(torch.float16).view(n, d), tr)
+        assert torch.equal(timg[off:off + 4 * n].view(torch.float32), ti)
+        want = ops.dist_argmin(xt, w, xxt, ee)
+        got = ops.dist_argmin_filtered(xt, w, xxt, ee, code_image=img_u, code_image_valid=True, token_image=timg)
+        assert torch.equal(got, want)
+        with pytest.raises(RuntimeError):
+            ops.dist_argmin_filtered(xt, w, None, ee, token_image=timg)                      # a token image needs xx
+
+
+def test_module_keeps_the_code_image_between_filtered_calls():
+    """Training and evaluation with search='filter': a module that keeps the codebook's image (written by every update,
+    read by the next search) equals one that does not, bit for bit, through state-dict loads and in-place writes; and
+    the encoder tail's token image changes nothing but the work."""
+    import copy
+    from t5vqvae_amd import VectorQuantizerEMA
+    from t5vqvae_amd import vqvae as hv
+    from t5vqvae_amd.encoder_tail import EncoderTailVQ
+    n, k, d = 8192, 2048, 768
+    a = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda()
+    a.encodings, a.search = "indices", "filter"
+    b = copy.deepcopy(a)
+    b.code_image_cache = False
+    w0 = synth.normal((k, d), 21, 0, device="cuda")
+    for m in (a, b):
+        with torch.no_grad():
+            m._embedding.weight.copy_(w0), m._ema_w.copy_(w0)
+
+    def both(x, train, call=lambda m, x: m(x)):
+        outs = []
+        for m in (a, b):
+            m.train(train)
+            outs.append(call(m, x))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+        exact = a.deterministic or not train           # embed_sum by fp32 atomics: last bits depend on arrival order
+        for name in ("_embedding.weight", "_ema_w", "_ema_cluster_size"):
+            u, v = a.state_dict()[name], b.state_dict()[name]
+            assert torch.equal(u, v) if exact else float((u - v).norm() / v.norm()) <= 1e-6, name
+        if not exact:                                  # same start for the next call: its outputs must be equal again
+            b.load_state_dict(a.state_dict())
+
+    for step in range(4):
+        x, _ = synth.clustered(n, a._embedding.weight.detach(), 0.7, 30 + step)
+        both(x.view(8, n // 8, d), True)
+        ent = hv._IMG_STATE[a]
+        assert ent[1] == a._embedding.weight.data_ptr() and ent[2] == a._embedding.weight._version   # valid for the next call
+    assert b not in hv._IMG_STATE
+    both(x.view(8, n // 8, d), False)
+    sd = {key: v.clone() for key, v in a.state_dict().items()}
+    sd["_embedding.weight"] = sd["_embedding.weight"] * 1.25
+    a.load_state_dict(sd), b.load_state_dict(sd)
+    both(x.view(8, n // 8, d), False)
+    both(x.view(8, n // 8, d), True)
+    for m in (a, b):
+        m._embedding.weight.data.mul_(0.5)
+        m.invalidate_code_norms()
+    both(x.view(8, n // 8, d), True)
+    a.deterministic = b.deterministic = True               # the fixed-point update writes the image as well
+    both(x.view(8, n // 8, d), True)
+    both(x.view(8, n // 8, d), False)
+    a.deterministic = b.deterministic = False
+    # encoder tail: token image from the norm kernel
+    ta, tb = EncoderTailVQ(a, hidden_size=d, dropout_rate=0.1).cuda(), EncoderTailVQ(b, hidden_size=d, dropout_rate=0.1).cuda()
+    tb._wants_image = lambda *args: False
+    h = synth.normal((8, n // 8, d), 40, 0, device="cuda")
+    keep = (torch.rand(8, n // 8, d, device="cuda") > 0.1)
+    both(h, True, call=lambda m, x: (ta if m is a else tb)(x, keep_mask=keep))
+    both(h, False, call=lambda m, x: (ta if m is a else tb).eval()(x))      # (eval: the tail draws no dropout mask)
+

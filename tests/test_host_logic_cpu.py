@@ -338,6 +338,82 @@ def test_encoder_tail_host_logic_and_autograd(monkeypatch):
     assert (tail.weight.grad - g2.grad).norm() / g2.grad.norm() < 1e-5
 
 
+def test_code_and_token_images_follow_the_codebook(monkeypatch):
+    """The module keeps the fp16 image of its codebook between filtered searches (written by the search that finds none,
+    rewritten by every EMA update, dropped by invalidate_code_norms) and hands the encoder tail's token image to the
+    search.  The stand-in kernels SEARCH THE IMAGE when told it is valid, so a stale image changes results: a module
+    with the cache must equal one without it through training, evaluation, a state-dict load, a tracked in-place write
+    and a .data write followed by invalidate_code_norms()."""
+    import copy
+    import fake_ops
+    from t5vqvae_amd import vqvae as hv, encoder_tail as et
+    monkeypatch.setattr(hv, "ops", fake_ops)
+    monkeypatch.setattr(et, "ops", fake_ops)
+    torch.manual_seed(1)
+    k, d = 40, 64
+    a = hv.VectorQuantizerEMA(k, d, 0.25, decay=0.9)
+    a.encodings, a.search = "indices", "filter"
+    b = copy.deepcopy(a)
+    b.code_image_cache = False
+    seen = []
+    real = fake_ops.fused_step
+
+    def spy(*args, **kw):
+        seen.append((kw.get("code_image") is not None, bool(kw.get("code_image_valid")), kw.get("token_image") is not None))
+        return real(*args, **kw)
+    monkeypatch.setattr(fake_ops, "fused_step", spy)
+
+    def both(x, train):
+        outs = []
+        for m in (a, b):
+            m.train(train)
+            outs.append(m(x))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+        assert torch.equal(a._embedding.weight, b._embedding.weight)
+
+    xs = [torch.randn(2, 30, d) for _ in range(8)]
+    both(xs[0], True)                                   # no image yet: the search makes it, the update rewrites it
+    both(xs[1], True)                                   # valid now
+    both(xs[2], False)
+    assert [s_ for s_ in seen if s_[0]] == [(True, False, False), (True, True, False), (True, True, False)]
+    sd = {key: v.clone() + 0.01 for key, v in a.state_dict().items()}
+    a.load_state_dict(sd), b.load_state_dict(sd)        # version bump: invalid, made again
+    both(xs[3], False)
+    assert seen[-2] == (True, False, False)
+    both(xs[3], False)
+    assert seen[-2] == (True, True, False)
+    with torch.no_grad():
+        for m in (a, b):
+            m._embedding.weight.mul_(1.5)               # tracked in-place write
+    both(xs[4], True)
+    assert seen[-2] == (True, False, False)
+    for m in (a, b):
+        m._embedding.weight.data.add_(0.25)             # invisible to the version counter ...
+        m.invalidate_code_norms()                       # ... so the caller says so
+    both(xs[5], True)
+    assert seen[-2] == (True, False, False)
+    a.search = b.search = "scan"                        # an update under the scan keeps the image current
+    both(xs[6], True)
+    assert seen[-2] == (True, False, False)
+    a.search = b.search = "filter"
+    both(xs[7], False)
+    assert seen[-2] == (True, True, False)
+
+    # the encoder tail hands its token image to the filtered search (and none to the scan)
+    tail_a, tail_b = et.EncoderTailVQ(a, hidden_size=d, dropout_rate=0.0), et.EncoderTailVQ(b, hidden_size=d, dropout_rate=0.0)
+    h = torch.randn(2, 30, d)
+    for m in (a, b):
+        m.eval()
+    ra, rb = tail_a(h), tail_b(h)
+    assert seen[-2] == (True, True, True) and seen[-1] == (False, False, True)
+    for u, v in zip(ra, rb):
+        assert torch.equal(u, v)
+    a.search = "scan"
+    tail_a(h)
+    assert seen[-1] == (False, False, False)
+
+
 def test_role_helpers_follow_the_loader():
     """t5/load_data.py:68-86 and t5/utils.py:22-44 on a hand-worked example."""
     from t5vqvae_amd import roles
