@@ -50,6 +50,10 @@ class EncoderTailVQ(nn.Module):
     ``vq``: a ``t5vqvae_amd`` quantizer module.  ``weight``: the ``final_layer_norm.weight`` Parameter to share (so
     checkpoints keep their key), or None for a fresh ``ones(hidden_size)`` (modeling_t5.py:197)."""
 
+    # the norm kernel also writes the fp16 image of its output from this many elements on: at C3 (5e7) tail + filtered
+    # step 1226 -> 1214 us; at C1 (2.2e6) the extra buffer and output cost more than the preparation pass they save
+    token_image_min_elements = 1 << 24
+
     def __init__(self, vq, hidden_size: int = 768, eps: float = 1e-6, dropout_rate: float = 0.1, weight=None):
         super().__init__()
         self.vq = vq
@@ -80,7 +84,7 @@ class EncoderTailVQ(nn.Module):
         guess costs one unused write of N * D * 2 bytes, or the usual preparation pass: never a result.)"""
         vq = self.vq
         search = getattr(vq, "search", "scan")
-        if search == "scan" or d % 64 or d > 2048:
+        if search == "scan" or d % 64 or d > 2048 or n * d < self.token_image_min_elements:
             return False
         if srl is not None and getattr(vq, "disentanglement", False) and n >= 1024:
             return False                       # role order: the search lays its image out in that order itself

@@ -215,7 +215,12 @@ class _QuantizerBase(nn.Module):
         _EE_STATE.pop(self, None)
         _IMG_STATE.pop(self, None)
 
-    code_image_cache = True      # False: every filtered search makes the codebook's fp16 image itself, in its workspace
+    # The codebook's fp16 image for the filtered search, kept between calls.  "eval" (default): calls WITHOUT an EMA
+    # update make it once and read it afterwards (the search's preparation pass then reads no codebook row); an update
+    # drops it.  "always": the update kernel also writes the image of the codebook it writes, so training calls read it
+    # too -- measured at C3 the update gets 10 us slower to save the preparation pass 5 us (K = 8192 code rows against
+    # 65536 token rows), so this pays only where K is large against N.  False: every search makes its own.
+    code_image_cache = "eval"
 
     def _images(self, w, ee, use_filter, update, ximg):
         """Keyword arguments about fp16 images for this call's ops: ``code_image`` / ``code_image_valid`` for the search
@@ -224,7 +229,13 @@ class _QuantizerBase(nn.Module):
         if ximg is not None and use_filter:
             out["token_image"] = ximg
         param = self._embedding.weight
-        if not self.code_image_cache or ee is None or w.data_ptr() != param.data_ptr() or w.shape[1] % 64:
+        mode = "always" if self.code_image_cache is True else self.code_image_cache
+        if mode not in (False, None, "eval", "always"):
+            raise ValueError(f"code_image_cache must be False, 'eval' or 'always', got {self.code_image_cache!r}")
+        if update and mode != "always":
+            _IMG_STATE.pop(self, None)                       # the update rewrites the codebook behind the image's back
+            return out
+        if not mode or ee is None or w.data_ptr() != param.data_ptr() or w.shape[1] % 64:
             return out
         ent = _IMG_STATE.get(self)
         if ent is not None and (ent[0].device != w.device or ent[3] != tuple(w.shape)):

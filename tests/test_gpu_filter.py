@@ -443,7 +443,7 @@ def test_module_keeps_the_code_image_between_filtered_calls():
     from t5vqvae_amd.encoder_tail import EncoderTailVQ
     n, k, d = 8192, 2048, 768
     a = VectorQuantizerEMA(k, d, 0.25, decay=0.99).cuda()
-    a.encodings, a.search = "indices", "filter"
+    a.encodings, a.search, a.code_image_cache = "indices", "filter", "always"
     b = copy.deepcopy(a)
     b.code_image_cache = False
     w0 = synth.normal((k, d), 21, 0, device="cuda")
@@ -487,6 +487,7 @@ def test_module_keeps_the_code_image_between_filtered_calls():
     a.deterministic = b.deterministic = False
     # encoder tail: token image from the norm kernel
     ta, tb = EncoderTailVQ(a, hidden_size=d, dropout_rate=0.1).cuda(), EncoderTailVQ(b, hidden_size=d, dropout_rate=0.1).cuda()
+    ta.token_image_min_elements = 0
     tb._wants_image = lambda *args: False
     h = synth.normal((8, n // 8, d), 40, 0, device="cuda")
     keep = (torch.rand(8, n // 8, d, device="cuda") > 0.1)

@@ -352,9 +352,10 @@ def test_code_and_token_images_follow_the_codebook(monkeypatch):
     torch.manual_seed(1)
     k, d = 40, 64
     a = hv.VectorQuantizerEMA(k, d, 0.25, decay=0.9)
-    a.encodings, a.search = "indices", "filter"
+    a.encodings, a.search, a.code_image_cache = "indices", "filter", "always"
     b = copy.deepcopy(a)
     b.code_image_cache = False
+    monkeypatch.setattr(et.EncoderTailVQ, "token_image_min_elements", 0)
     seen = []
     real = fake_ops.fused_step
 
@@ -412,6 +413,15 @@ def test_code_and_token_images_follow_the_codebook(monkeypatch):
     a.search = "scan"
     tail_a(h)
     assert seen[-1] == (False, False, False)
+
+    # default mode "eval": evaluation calls keep the image, an update drops it and writes none
+    c = copy.deepcopy(b)
+    c.code_image_cache, c.search = "eval", "filter"
+    for train, want in ((False, (True, False, False)), (False, (True, True, False)), (True, (False, False, False)),
+                        (False, (True, False, False)), (False, (True, True, False))):
+        c.train(train)
+        c(xs[0])
+        assert seen[-1] == want, (train, seen[-1])
 
 
 def test_role_helpers_follow_the_loader():

@@ -52,16 +52,27 @@ def main():
                 m._embedding.weight.copy_(w), m._ema_w.copy_(ema_w), m._ema_cluster_size.copy_(cs)
             m.encodings = "indices"
             return m.train(update)
-        vq_a, vq_b = make(), make()
+        vq_a, vq_b, vq_c = make(), make(), make()
+        vq_b.code_image_cache = "always"      # the update writes the codebook's image too (default: evaluation only)
+        vq_c.code_image_cache = False
         ln, drop = EagerT5LayerNorm(d).to(dev), torch.nn.Dropout(0.1)
         tail = EncoderTailVQ(vq_b, hidden_size=d, dropout_rate=0.1).to(dev).train()
+        tail_c = EncoderTailVQ(vq_c, hidden_size=d, dropout_rate=0.1).to(dev).train()   # no images from the producers
+        tail_c._wants_image = lambda *a: False
+        tail.token_image_min_elements = 0
         with torch.no_grad():
             t_tail_eager = timed(lambda: drop(ln(h)))
             t_eager = timed(lambda: vq_a(drop(ln(h))))
             t_fused = timed(lambda: tail(h))
-            t_vq = timed(lambda: vq_a(x))
-        print(f"{name}: eager tail alone {t_tail_eager:8.1f} us | eager tail + VQ {t_eager:8.1f} us | fused tail + VQ "
-              f"{t_fused:8.1f} us | VQ alone {t_vq:8.1f} us", flush=True)
+            t_fused_c = timed(lambda: tail_c(h))
+            t_vq = timed(lambda: vq_b(x))
+            t_vq_c = timed(lambda: vq_c(x))
+            vq_a.eval(), vq_c.eval()
+            t_ev, t_ev_c = timed(lambda: vq_a(x)), timed(lambda: vq_c(x))
+        print(f"{name} (search={vq_a.search}): eager tail alone {t_tail_eager:8.1f} us | eager tail + VQ {t_eager:8.1f} us | "
+              f"fused tail + VQ {t_fused:8.1f} us (without fp16 images from the producers {t_fused_c:8.1f}) | VQ step alone, "
+              f"code image written by the update {t_vq:8.1f} us (no kept image {t_vq_c:8.1f}) | evaluation call, kept code "
+              f"image {t_ev:8.1f} us (none {t_ev_c:8.1f})", flush=True)
 
 
 if __name__ == "__main__":
