@@ -400,7 +400,8 @@ def c5_grouped_shard_config(dev, role_set, search, iters, check):
            "dense_flops": 2.0 * n * kl * d,
            "frac_of_mfma_roofline": (flops / PEAK_FP32_MFMA_TFLOPS / 1e12) / (med * 1e-3),
            "other_search": {"search": other, "ms_per_call_median": omed,
-                            "indices_identical": bool(torch.equal(keys & 0xFFFFFFFF, okeys & 0xFFFFFFFF))}}
+                            "indices_identical_to_headline_mode": bool(torch.equal(keys & 0xFFFFFFFF,
+                                                                                    okeys & 0xFFFFFFFF))}}
     if check:
         from oracle import vq_oracle as vo
         ns = 2048

@@ -1473,8 +1473,8 @@ __global__ __launch_bounds__(1024) void ema_cluster_kernel(float* __restrict__ c
 // reads no fp32 codebook row for its preparation): what filter_prep_kernel would make of the row, bit for bit -- the
 // same scale rule on the same values, sqrt of the same |e|^2.  qv: the row in registers, float4 #(lane + 64 j)
 // (D <= 2048: the launcher refuses an image beyond); m: the lane's largest magnitude, sq: |e_row|^2.
-constexpr int IMG_NCH = 8;
-__device__ __forceinline__ void emit_code_image_row(const T5vqCodeImage& img, const f32x4 (&qv)[IMG_NCH], long long row,
+template <int NCH>
+__device__ __forceinline__ void emit_code_image_row(const T5vqCodeImage& img, const f32x4 (&qv)[NCH], long long row,
                                                     int D, int lane, float m, float sq) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -1486,7 +1486,7 @@ __device__ __forceinline__ void emit_code_image_row(const T5vqCodeImage& img, co
     }
     _Float16* dst = img.rows + row * D;
 #pragma unroll
-    for (int j = 0; j < IMG_NCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int i = lane + 64 * j;
         if (i < (D >> 2)) t5vq_image_store4(dst, i, qv[j].x, qv[j].y, qv[j].z, qv[j].w, scale);
     }
@@ -1496,13 +1496,14 @@ __device__ __forceinline__ void emit_code_image_row(const T5vqCodeImage& img, co
 // ee_out (nullable): |e_row|^2 of the row just written, accumulated in row_sqnorm_wave's lane layout and order from
 // the values in registers -- bit-identical to t5vq_row_sqnorms_f32 run on the new codebook, so the next call need not
 // read the codebook for its norms (vqvae/vqvae.py:107 recomputes them every call).
+template <int NCH>   // NCH > 0: also write the row's fp16 image, the row held in NCH float4 per lane (D <= 256 NCH); 0: no image
 __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
                                                         const float* __restrict__ dw, const float* __restrict__ cs,
                                                         int K, int D, float decay, float omd,
                                                         float* __restrict__ ee_out, T5vqCodeImage img, int kpad) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (img.rows && blockIdx.x == 0)   // the image's padding entries: inverse scale 1, sqrt(|e|^2) = +inf
+    if (NCH > 0 && blockIdx.x == 0)   // the image's padding entries: inverse scale 1, sqrt(|e|^2) = +inf
         for (int r = K + threadIdx.x; r < kpad; r += blockDim.x) {
             img.inv[r] = 1.0f;
             img.se[r] = __int_as_float(0x7F800000);
@@ -1529,10 +1530,10 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
         sq = sq4(q, sq);
         return q;
     };
-    if (img.rows) {   // D <= 2048: the row stays in registers for its image
-        f32x4 qv[IMG_NCH];
+    if constexpr (NCH > 0) {   // the row stays in registers for its image
+        f32x4 qv[NCH];
 #pragma unroll
-        for (int j = 0; j < IMG_NCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             const int i = lane + 64 * j;
             if (i < (D >> 2)) {
                 qv[j] = one(i);
@@ -1541,7 +1542,7 @@ __global__ __launch_bounds__(256) void ema_embed_kernel(float* __restrict__ ema_
         }
         sq = wave_sum(sq);
         if (ee_out && lane == 0) ee_out[row] = sq;
-        emit_code_image_row(img, qv, row, D, lane, m, sq);
+        emit_code_image_row<NCH>(img, qv, row, D, lane, m, sq);
         return;
     }
     for (int i = lane; i < (D >> 2); i += 64) one(i);
@@ -1793,6 +1794,7 @@ __global__ __launch_bounds__(256) void embed_sum_fixed_kernel(const float* __res
 }
 
 // K4b for the fixed-point statistics: dw = the exact sum, rounded once
+template <int NCH>
 __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict__ ema_w, float* __restrict__ w,
                                                               const long long* __restrict__ dw,
                                                               const int* __restrict__ max_xx_bits,
@@ -1801,7 +1803,7 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
                                                               int kpad) {
     const int lane = threadIdx.x & 63;
     const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (img.rows && blockIdx.x == 0)
+    if (NCH > 0 && blockIdx.x == 0)
         for (int r = K + threadIdx.x; r < kpad; r += blockDim.x) {
             img.inv[r] = 1.0f;
             img.se[r] = __int_as_float(0x7F800000);
@@ -1824,10 +1826,10 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
         sq = sq4(q, sq);
         return q;
     };
-    if (img.rows) {   // D <= 2048: the row stays in registers for its image
-        f32x4 qv[IMG_NCH];
+    if constexpr (NCH > 0) {   // the row stays in registers for its image
+        f32x4 qv[NCH];
 #pragma unroll
-        for (int j = 0; j < IMG_NCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             const int i4 = lane + 64 * j;
             if (i4 < (D >> 2)) {
                 qv[j] = one(i4);
@@ -1836,7 +1838,7 @@ __global__ __launch_bounds__(256) void ema_embed_fixed_kernel(float* __restrict_
         }
         sq = wave_sum(sq);
         if (ee_out && lane == 0) ee_out[row] = sq;
-        emit_code_image_row(img, qv, row, D, lane, m, sq);
+        emit_code_image_row<NCH>(img, qv, row, D, lane, m, sq);
         return;
     }
     for (int i4 = lane; i4 < (D >> 2); i4 += 64) one(i4);
@@ -2518,10 +2520,20 @@ int t5vq_ema_embed_img_f32(float* ema_w, float* w, const float* embed_sum, const
     T5VQ_REQUIRE(aligned16(ema_w) && aligned16(w) && aligned16(embed_sum), "buffers must be 16-byte aligned");
     T5VQ_REQUIRE((reinterpret_cast<uintptr_t>(code_image) & 255u) == 0, "code_image must be 256-byte aligned");
     T5VQ_REQUIRE(!code_image || D <= 2048, "the update writes a code image for D <= 2048 only");
-    hipLaunchKernelGGL(ema_embed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),
-                       static_cast<int>(D), decay, one_minus_decay, ee_out, t5vq_code_image_parts(code_image, K, D),
-                       static_cast<int>(t5vq_padded_codes(K)));
+#define T5VQ_EE(IMG_)                                                                                              \
+    hipLaunchKernelGGL((ema_embed_kernel<IMG_>), dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,              \
+                       static_cast<hipStream_t>(stream), ema_w, w, embed_sum, cluster_size, static_cast<int>(K),     \
+                       static_cast<int>(D), decay, one_minus_decay, ee_out, t5vq_code_image_parts(code_image, K, D), \
+                       static_cast<int>(t5vq_padded_codes(K)))
+    switch (code_image ? pick_nch(D) : 0) {   // D <= 2048 with an image (checked above)
+        case 0: T5VQ_EE(0); break;
+        case 1: T5VQ_EE(1); break;
+        case 2: T5VQ_EE(2); break;
+        case 3: T5VQ_EE(3); break;
+        case 4: T5VQ_EE(4); break;
+        default: T5VQ_EE(8); break;
+    }
+#undef T5VQ_EE
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }
@@ -2591,10 +2603,20 @@ int t5vq_ema_embed_fixed_img_f32(float* ema_w, float* w, const int64_t* embed_su
     T5VQ_REQUIRE(!code_image || (aligned16(w) && (reinterpret_cast<uintptr_t>(code_image) & 255u) == 0),
                  "code_image must be 256-byte aligned (and w 16-byte aligned)");
     T5VQ_REQUIRE(!code_image || D <= 2048, "the update writes a code image for D <= 2048 only");
-    hipLaunchKernelGGL(ema_embed_fixed_kernel, dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), ema_w, w, reinterpret_cast<const long long*>(embed_sum),
-                       max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay,
-                       ee_out, t5vq_code_image_parts(code_image, K, D), static_cast<int>(t5vq_padded_codes(K)));
+#define T5VQ_EF(IMG_)                                                                                               \
+    hipLaunchKernelGGL((ema_embed_fixed_kernel<IMG_>), dim3(static_cast<unsigned>((K + 3) / 4)), dim3(256), 0,         \
+                       static_cast<hipStream_t>(stream), ema_w, w, reinterpret_cast<const long long*>(embed_sum),     \
+                       max_xx_bits, cluster_size, static_cast<int>(K), static_cast<int>(D), decay, one_minus_decay,   \
+                       ee_out, t5vq_code_image_parts(code_image, K, D), static_cast<int>(t5vq_padded_codes(K)))
+    switch (code_image ? pick_nch(D) : 0) {
+        case 0: T5VQ_EF(0); break;
+        case 1: T5VQ_EF(1); break;
+        case 2: T5VQ_EF(2); break;
+        case 3: T5VQ_EF(3); break;
+        case 4: T5VQ_EF(4); break;
+        default: T5VQ_EF(8); break;
+    }
+#undef T5VQ_EF
     T5VQ_CHECK_HIP(hipGetLastError());
     return T5VQ_OK;
 }

@@ -414,7 +414,7 @@ def test_code_and_token_images_follow_the_codebook(monkeypatch):
     tail_a(h)
     assert seen[-1] == (False, False, False)
 
-    # default mode "eval": evaluation calls keep the image, an update drops it and writes none
+    # mode "eval": evaluation calls keep the image, an update drops it and writes none
     c = copy.deepcopy(b)
     c.code_image_cache, c.search = "eval", "filter"
     for train, want in ((False, (True, False, False)), (False, (True, True, False)), (True, (False, False, False)),

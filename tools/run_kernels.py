@@ -48,6 +48,8 @@ else:
         mod._ema_cluster_size.copy_(cs)
         mod.encodings = "indices"
         mod.search = search
+        if os.environ.get("T5VQ_CODE_IMAGE"):               # "always": the update writes the codebook's fp16 image too
+            mod.code_image_cache = os.environ["T5VQ_CODE_IMAGE"]
         mod.train(update)
         for _ in range(reps):
             mod(x)
