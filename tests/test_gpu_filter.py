@@ -330,13 +330,20 @@ def test_filtered_keys_identical_to_scan_on_random_shapes():
                 a = synth.uniform_int(n, k, 700 + i, 0, "cuda")
                 b = synth.uniform_int(n, k, 700 + i, 1, "cuda")
                 x = 0.5 * (w[a] + w[b]) + 1e-4 * synth.normal((n, d), 600 + i, 0, device="cuda")
-            rg = None
+            rg, off, order = None, 0, None
             if ranged:
-                cut = max(1, k // 3)
-                rg = synth.role_ranges(n, [(0, cut), (cut, k), (0, k), (cut, cut)], 800 + i, 0, device="cuda")
+                # the codebook is a slice [off, off + k) of a larger one: roles inside it, across its borders, beside it
+                # (workgroups of the ranged filter whose code split misses their tokens' ranges write no records)
+                off = (0, 0, 300, 4096)[i % 4]
+                cut, top = off + max(1, k // 3), off + k
+                roles = [(off, cut), (cut, top), (off, top), (cut, cut), (max(0, off - 200), off + 1),
+                         (top - 1, top + 700), (top + 5, top + 900), (0, off)]
+                rg = synth.role_ranges(n, roles[:4] if off == 0 else roles, 800 + i, 0, device="cuda").contiguous()
+                if i % 2:
+                    order = ops.order_by_range(rg, k, off)
             xx, ee = ops.row_sqnorms(x, w)
-            scan = ops.dist_argmin(x, w, xx, ee, rg)
-            filt = ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg)
+            scan = ops.dist_argmin(x, w, xx, ee, rg, code_offset=off, order=order)
+            filt = ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg, code_offset=off, order=order)
             if not torch.equal(scan, filt):
                 bad.append((rep, n, k, d, ranged, regime, int((scan != filt).sum())))
     assert not bad, bad
