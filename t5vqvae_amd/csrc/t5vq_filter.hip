@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
                                                           long long kpad, float* __restrict__ se, int D,
                                                           int* __restrict__ n_list, int* __restrict__ tshare,
                                                           unsigned row_blocks, T5vqZeroArgs zero, int norm_x,
-                                                          int norm_w, const int* __restrict__ order, int have_x_image) {
+                                                          int norm_w, const int* __restrict__ order, int have_x_image,
+                                                          const long long* __restrict__ range, long long code_lo,
+                                                          long long code_hi) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= row_blocks) {   // the tail of the grid zeroes the caller's buffers: 4096 words per workgroup
         long long i = (static_cast<long long>(blockIdx.x - row_blocks) * 256 + threadIdx.x) * 16;
@@ -119,6 +121,12 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const float* __restric
         src = x + token * D; dst = xh + row * D; inv = x_inv + row; norm = xx + token;
         if (lane == 0) tshare[row] = 0x7F800000;   // order image of +inf: no bound yet
         if (have_x_image) return;                  // the producer of x wrote this row's image (and |x|^2 is given)
+        // ranged search on a codebook slice: a token whose range holds no code of the slice is never scored (its codes
+        // are all masked), so its image row is not made -- one code shard of a grouped codebook sees one token in eight
+        if (range && !norm_x) {
+            const long long a = range[2 * token], e = range[2 * token + 1];
+            if ((e < code_hi ? e : code_hi) <= (a > code_lo ? a : code_lo)) return;
+        }
     } else {
         row -= n_x;
         if (row >= kpad) return;
@@ -645,15 +653,17 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
 __device__ __forceinline__ float exact_distance(const float* __restrict__ xr, const float* __restrict__ wr, int D,
                                                 float xxv, float eev) {
     float dot = 0.f;
-    for (int k = 0; k < D; k += 32) {   // D % 64 == 0; the 16 loads of an iteration are issued before its fma chain
-        f32x4 xq[8], wq[8];
+    // D % 64 == 0; the 32 loads of an iteration (64 elements of both rows) are issued before its fma chain: a lane's rows
+    // are its own (uncoalesced 16-byte pieces), the chain is latency-bound and the loads are what can overlap
+    for (int k = 0; k < D; k += 64) {
+        f32x4 xq[16], wq[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
             xq[i] = *reinterpret_cast<const f32x4*>(xr + k + 4 * i);
             wq[i] = *reinterpret_cast<const f32x4*>(wr + k + 4 * i);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 8; ++g) {
             const f32x4 x0 = xq[2 * g], x1 = xq[2 * g + 1], w0 = wq[2 * g], w1 = wq[2 * g + 1];
             dot = fmaf(w0.x, x0.x, dot);
             dot = fmaf(w1.x, x1.x, dot);
@@ -855,6 +865,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     int* n_list = reinterpret_cast<int*>(base + ws.nlist);
     int* tshare = reinterpret_cast<int*>(base + ws.tshare);
     const int64_t kpad = t5vq_padded_codes(K);
+    const long long* rg = reinterpret_cast<const long long*>(range);
 
     {
         // x rows (with a token image: only their shared-bound slots are reset), then -- unless the codebook's image is
@@ -877,7 +888,8 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     hipLaunchKernelGGL((filter_prep_kernel<NCH_>), pgrid, dim3(256), 0, stream, x, static_cast<long long>(N), xb, \
                        x_inv, w, static_cast<long long>(K), wb, w_inv, xx, ee,                                   \
                        static_cast<long long>(have_w_image ? 0 : kpad), se, static_cast<int>(D), n_list, tshare,   \
-                       row_blocks, zero, norm_x, norm_w, order, have_x_image ? 1 : 0)
+                       row_blocks, zero, norm_x, norm_w, order, have_x_image ? 1 : 0, rg,                           \
+                       static_cast<long long>(code_offset), static_cast<long long>(code_offset + K))
         if (nch <= 1) { T5VQ_PREP(1); }
         else if (nch <= 2) { T5VQ_PREP(2); }
         else if (nch <= 3) { T5VQ_PREP(3); }
@@ -906,7 +918,6 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     const int64_t tiles_per_split = (code_tiles + splits - 1) / splits;
     const int plain_map = tok_tiles * splits <= 1024 ? 1 : 0;
     const dim3 grid(static_cast<unsigned>(plain_map ? tok_tiles * splits : (tok_tiles + 7) / 8 * 8 * splits));
-    const long long* rg = reinterpret_cast<const long long*>(range);
 #define T5VQ_FILTER_ARGS                                                                                              \
     reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), xx, ee, se, x_inv, w_inv,                 \
         static_cast<int>(N), static_cast<int>(K), static_cast<int>(kpad), static_cast<int>(D / 2),                    \
