@@ -236,6 +236,38 @@ def test_filtered_ranged_search_on_a_code_shard_where_most_tokens_belong_elsewhe
     assert torch.equal(inside, scan != 0x7FFFFFFFFFFFFFFF)
 
 
+def test_role_order_with_more_distinct_ranges_than_a_workgroup_table_holds():
+    """t5vq_order_by_range aggregates a workgroup's tokens per (start, end) bucket in a 64-entry LDS table and sends what
+    does not fit straight to memory: per-token random ranges put hundreds of distinct buckets into every workgroup.  The
+    order must be a permutation with the tokens of a bucket adjacent, and the ranged searches must not care."""
+    from t5vqvae_amd import ops
+    n, k, d = 7000, 16384, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randint(0, k, (n,), device="cuda", generator=g)
+    e = torch.randint(0, k, (n,), device="cuda", generator=g)
+    lo, hi = torch.minimum(a, e), torch.maximum(a, e) + torch.randint(0, 2, (n,), device="cuda", generator=g)
+    rg = torch.stack([lo, hi], 1).contiguous()                      # a few empty ranges (hi == lo) among them
+    order = ops.order_by_range(rg, k)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device="cuda"))
+    shift = 7                                                       # the library's bucket granularity: 128 codes, doubled
+    while True:                                                     # until the T (T + 1) + 1 buckets fit its K + 8 words
+        t = (k + (1 << shift) - 1) >> shift
+        if t * (t + 1) + 1 + 2 <= k + 8:
+            break
+        shift += 1
+    aa, ee_ = lo.clamp(0, k), hi.clamp(0, k)
+    bucket = torch.where(ee_ > aa, (aa >> shift) * (t + 1) + ((ee_ + (1 << shift) - 1) >> shift),
+                         torch.full_like(aa, t * (t + 1)))
+    assert int(bucket.unique().numel()) > 1000
+    assert bool((bucket[order.long()].diff() >= 0).all())
+    w = synth.normal((k, d), 12, 0, device="cuda")
+    x = synth.normal((n, d), 13, 0, device="cuda")
+    xx, ee = ops.row_sqnorms(x, w)
+    ref = ops.dist_argmin(x, w, xx, ee, rg)
+    assert torch.equal(ops.dist_argmin(x, w, xx, ee, rg, order=order), ref)
+    assert torch.equal(ops.dist_argmin_filtered(x, w, xx, ee, ranges=rg, order=order), ref)
+
+
 def test_disentangled_module_filter_equals_scan():
     from t5vqvae_amd import VectorQuantizerEMA
     n, k, d = 8192, 4096, 768
