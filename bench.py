@@ -374,7 +374,8 @@ def c5_grouped_shard_config(dev, role_set, search, iters, check):
         order = ops.order_by_range(rg, kl, off)
         if mode == "scan":
             return ops.dist_argmin(x, w, xx, ee, rg, code_offset=off, order=order)
-        return ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True)
+        return ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True,
+                                        range_sparse=True)     # as the code-sharded module calls it on a shard
 
     def timed(mode):
         ts = []

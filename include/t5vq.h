@@ -379,6 +379,9 @@ int t5vq_vq_ema_finalize_f32(float* cluster_size, float* ema_w, float* w, const 
  *     x it produces (python_transformers/modeling_t5.py:864-865); a search given one needs xx as an input and ignores
  *     it when the tokens are visited in role order (order != NULL, or ranges in the composite forward from 1024 tokens).
  * Images are bit-identical to the ones the search makes itself, so are all results (tests/test_gpu_filter.py).
+ * range_sparse (t5vq_dist_argmin_filtered_img_f32, ranged search only): != 0 when the caller expects most tokens' ranges
+ *   to miss this codebook slice (one code shard of a disentangled codebook): the codes are then cut into more, smaller
+ *   pieces so that the few token tiles with work fill the chip.  A performance hint: the keys do not depend on it.
  * Every other argument as in the form without _img. */
 int64_t t5vq_code_image_bytes(int64_t K, int64_t D);
 int64_t t5vq_token_image_bytes(int64_t N, int64_t D);
@@ -386,7 +389,7 @@ int t5vq_dist_argmin_filtered_img_f32(const float* x, const float* w, float* xx,
                                       const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
                                       int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
                                       int64_t* keys, int32_t* n_overflow, void* code_image, int code_image_valid,
-                                      const void* token_image, t5vq_stream_t stream);
+                                      const void* token_image, int range_sparse, t5vq_stream_t stream);
 int t5vq_vq_forward_filtered_img_f32(const float* x, const float* w, const int64_t* range, const float* xx_in,
                                      const float* ee_in, int64_t N, int64_t K, int64_t D, int loss_kind,
                                      void* workspace, int64_t workspace_bytes, float* out_ste, float* out_q,

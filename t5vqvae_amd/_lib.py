@@ -53,7 +53,7 @@ SIGNATURES = {
     "t5vq_code_image_bytes": (I64, [I64, I64]),
     "t5vq_token_image_bytes": (I64, [I64, I64]),
     "t5vq_dist_argmin_filtered_img_f32": (c_int, [P, P, P, P, c_int, P, P, I64, I64, I64, I64, c_int, P, I64, P, P, P,
-                                                  c_int, P, P]),
+                                                  c_int, P, c_int, P]),
     "t5vq_ema_embed_img_f32": (c_int, [P, P, P, P, I64, I64, c_float, c_float, P, P, P]),
     "t5vq_ema_embed_fixed_img_f32": (c_int, [P, P, P, P, P, I64, I64, c_float, c_float, P, P, P]),
     "t5vq_rmsnorm_backward_blocks": (I64, [I64]),

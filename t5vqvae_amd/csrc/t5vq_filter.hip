@@ -742,13 +742,14 @@ constexpr int MIN_TILES = 1;
 // after reading the ranges (no scanner records: collect_kernel skips the splits a token's range misses), and the
 // dispatcher hands the others out as compute units free up.  4 pieces: that shard 328 us, whole codebooks of 8192 ..
 // 65536 codes level or up to 1.35x faster; 8 is better on the aligned shard (266 us) and worse elsewhere
-// (tools/experiments/ranged_filter_splits.py, profiles/r3_ranged_filter_splits.txt).
-constexpr int64_t RANGED_SPLITS = 4;
-int64_t plan_filter_splits(int64_t N, int64_t K, bool ranged) {
+// (tools/experiments/ranged_filter_splits.py, profiles/r3_ranged_filter_splits.txt) -- the host does not see the
+// ranges, so a caller who knows that most tokens belong elsewhere (a code shard) says so: sparse -> 8 pieces.
+constexpr int64_t RANGED_SPLITS = 4, RANGED_SPLITS_SPARSE = 8;
+int64_t plan_filter_splits(int64_t N, int64_t K, bool ranged, bool sparse = false) {
     const int64_t tok_tiles = (N + TOK_TILE - 1) / TOK_TILE;
     const int64_t code_tiles = (K + CODE_TILE - 1) / CODE_TILE;
     if (ranged) {
-        int64_t s = RANGED_SPLITS;
+        int64_t s = sparse ? RANGED_SPLITS_SPARSE : RANGED_SPLITS;
 #ifdef T5VQ_TUNING
         if (const char* e = getenv("T5VQ_RANGED_SPLITS")) s = atoi(e);
 #endif
@@ -773,7 +774,7 @@ extern "C" {
 
 int64_t t5vq_filter_workspace_bytes(int64_t N, int64_t K, int64_t D) {
     if (N < 0 || K < 0 || D < 0) return 0;
-    const int64_t a = plan_filter_splits(N, K, false), b = plan_filter_splits(N, K, true);   // the call may be either
+    const int64_t a = plan_filter_splits(N, K, false), b = plan_filter_splits(N, K, true, true);   // the call may be any
     return FilterWorkspace(N, K, D, 4 * (a > b ? a : b)).total;
 }
 
@@ -783,7 +784,7 @@ int t5vq_dist_argmin_filtered_f32(const float* x, const float* w, float* xx, flo
                                   int64_t* keys, int32_t* n_overflow, t5vq_stream_t stream_) {
     T5vqZeroArgs zero = {};
     return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, order, N, K, D, code_offset, exact_keys,
-                                              workspace, workspace_bytes, keys, n_overflow, zero, nullptr, 0, nullptr,
+                                              workspace, workspace_bytes, keys, n_overflow, zero, nullptr, 0, nullptr, 0,
                                               static_cast<hipStream_t>(stream_));
 }
 
@@ -799,18 +800,20 @@ int t5vq_dist_argmin_filtered_img_f32(const float* x, const float* w, float* xx,
                                       const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
                                       int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
                                       int64_t* keys, int32_t* n_overflow, void* code_image, int code_image_valid,
-                                      const void* token_image, t5vq_stream_t stream_) {
+                                      const void* token_image, int range_sparse, t5vq_stream_t stream_) {
     T5vqZeroArgs zero = {};
     return t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, order, N, K, D, code_offset, exact_keys,
                                               workspace, workspace_bytes, keys, n_overflow, zero, code_image,
-                                              code_image_valid, token_image, static_cast<hipStream_t>(stream_));
+                                              code_image_valid, token_image, range_sparse,
+                                              static_cast<hipStream_t>(stream_));
 }
 
 int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
                                        const int64_t* range, const int32_t* order, int64_t N, int64_t K, int64_t D,
                                        int64_t code_offset, int exact_keys, void* workspace, int64_t workspace_bytes,
                                        int64_t* keys, int32_t* n_overflow, T5vqZeroArgs zero, void* code_image,
-                                       int code_image_valid, const void* token_image, hipStream_t stream) {
+                                       int code_image_valid, const void* token_image, int range_sparse,
+                                       hipStream_t stream) {
     T5VQ_I_REQUIRE(x && w && xx && ee && keys && workspace, "null pointer");
     if (order) token_image = nullptr;   // the search walks image rows in role order: an image in token order is no use
     const bool have_w_image = code_image && code_image_valid;
@@ -829,7 +832,7 @@ int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx
     T5VQ_I_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0 &&
                        (reinterpret_cast<uintptr_t>(ee) & 15u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
                    "x, w, ee must be 16-byte aligned and the workspace 256-byte aligned");
-    const int64_t splits = plan_filter_splits(N, K, range != nullptr);
+    const int64_t splits = plan_filter_splits(N, K, range != nullptr, range_sparse != 0);
     const int64_t scanners = 4 * splits;
     const FilterWorkspace ws(N, K, D, scanners);
     T5VQ_I_REQUIRE(workspace_bytes >= ws.total, "workspace smaller than t5vq_filter_workspace_bytes(N, K, D)");

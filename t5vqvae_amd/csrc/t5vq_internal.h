@@ -19,12 +19,13 @@ struct T5vqZeroArgs {
 };
 // code_image (nullable) with code_image_valid != 0: the codebook's image is read from the block; == 0: the call
 // writes it there (for the next call).  token_image (nullable): a valid image of x in token order (ignored with order).
+// range_sparse: the caller expects most tokens' ranges to miss this codebook slice (more, smaller code splits).
 extern "C" int t5vq_internal_dist_argmin_filtered(const float* x, const float* w, float* xx, float* ee, int compute_norms,
                                                   const int64_t* range, const int32_t* order, int64_t N, int64_t K,
                                                   int64_t D, int64_t code_offset, int exact_keys, void* workspace,
                                                   int64_t workspace_bytes, int64_t* keys, int32_t* n_overflow,
                                                   T5vqZeroArgs zero, void* code_image, int code_image_valid,
-                                                  const void* token_image, hipStream_t stream);
+                                                  const void* token_image, int range_sparse, hipStream_t stream);
 
 // ---- fp16 images of rows for the filtered search (t5vq_filter.hip); the kernels that produce the rows (codebook
 // update, fused encoder tail) can emit them, so the search's preparation pass need not read those rows again.

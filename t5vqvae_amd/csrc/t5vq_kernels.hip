@@ -3080,7 +3080,7 @@ int t5vq_vq_forward_filtered_img_f32(const float* x, const float* w, const int64
     }
     int rc = t5vq_internal_dist_argmin_filtered(x, w, xx, ee, compute_norms, range, role_order, N, K, D, 0, 0,
                                                 base + ws.total, filter_bytes, keys, n_overflow, zero, code_image,
-                                                code_image_valid, token_image, stream);
+                                                code_image_valid, token_image, 0, stream);
     if (rc != T5VQ_OK) return rc;
     const int32_t* perm = nullptr;
     if (order) {

@@ -132,7 +132,7 @@ def dist_argmin(x, w, xx, ee, ranges=None, code_offset: int = 0, keys=None, merg
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool = False, exact_keys: bool = True,
                          ranges=None, code_offset: int = 0, return_norms: bool = False, order=None,
-                         code_image=None, code_image_valid: bool = False, token_image=None):
+                         code_image=None, code_image_valid: bool = False, token_image=None, range_sparse: bool = False):
     """Same keys as ``dist_argmin(x, w, xx, ee)``, found by filtering in fp16 and deciding in fp32
     (t5vq_dist_argmin_filtered_f32).  ``xx`` / ``ee`` None (either or both): that norm is computed by the call's own
     first pass (no separate ``row_sqnorms``); a given norm is only read.  ``exact_keys=False``: only the index word is
@@ -140,7 +140,8 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
     Returns keys, or (keys, n_overflow int32[1]) with ``want_overflow``; ``return_norms`` appends (xx, ee) -- the
     norms the search used, whether given or computed.  ``code_image`` (a ``code_image()`` block): the codebook's fp16
     image is read from it when ``code_image_valid`` (``ee`` must be given), else this call writes it there;
-    ``token_image``: a valid image of x from its producer (``xx`` must be given; ignored with ``order``)."""
+    ``token_image``: a valid image of x from its producer (``xx`` must be given; ignored with ``order``).
+    ``range_sparse``: a hint that most tokens' ranges miss this codebook slice (a code shard): more, smaller code splits."""
     lib = _lib.load()
     _need(x, "x", ndim=2), _need(w, "w", ndim=2)
     n, d = x.shape
@@ -177,7 +178,8 @@ def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow: bool 
         _lib.check(lib.t5vq_dist_argmin_filtered_img_f32(_p(x), _p(w), _p(xx), _p(ee), compute, _p(ranges), _p(order),
                                                          n, k, d, code_offset, 1 if exact_keys else 0, _p(ws), nbytes,
                                                          _p(keys), _p(ovf), _p(code_image),
-                                                         1 if code_image_valid else 0, _p(token_image), _stream(x)),
+                                                         1 if code_image_valid else 0, _p(token_image),
+                                                         1 if range_sparse else 0, _stream(x)),
                    "dist_argmin_filtered")
     out = (keys, ovf) if want_overflow else (keys,)
     if return_norms:

@@ -182,7 +182,9 @@ class CodeShardedVectorQuantizerEMA(_QuantizerBase):
         _FULL_STATE[self] = (ent[0], ent[1], ent[2], work)
 
     def _global_keys(self, x, w_local, ranges):
-        keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin)
+        # a code shard of a disentangled codebook: most tokens' roles live on other shards (a hint for the filtered search)
+        sparse = {"range_sparse": True} if (ranges is not None and self.world >= 4) else None
+        keys = self._nearest_keys(x, w_local, ranges, code_offset=self.code_begin, images=sparse)
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return self._absolute(keys, ranges)
 

@@ -101,7 +101,8 @@ def _through_images(x, w, code_image, code_image_valid, token_image):
 
 
 def dist_argmin_filtered(x, w, xx=None, ee=None, keys=None, want_overflow=False, exact_keys=True, ranges=None,
-                         code_offset=0, order=None, code_image=None, code_image_valid=False, token_image=None):
+                         code_offset=0, order=None, code_image=None, code_image_valid=False, token_image=None,
+                         range_sparse=False):
     assert not code_image_valid or ee is not None
     assert token_image is None or xx is not None
     x, w = _through_images(x, w, code_image, code_image_valid, None if order is not None else token_image)

@@ -28,7 +28,8 @@ if workload.startswith("ranged"):
         if search == "scan":
             ops.dist_argmin(x, w, xx, ee, rg, code_offset=off, order=order)
         else:
-            ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True)
+            ops.dist_argmin_filtered(x, w, xx=xx, ee=ee, ranges=rg, code_offset=off, order=order, exact_keys=True,
+                                     range_sparse=os.environ.get("T5VQ_RANGE_SPARSE", "1") == "1")
     torch.cuda.synchronize()
     print(f"done {role_set} {search} algorithmic_flops={flops:.6g}")
     sys.exit(0)
