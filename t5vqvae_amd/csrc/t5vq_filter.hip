@@ -564,6 +564,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(const float* _
             active = false;
         }
     }
+    // a workgroup whose tokens all miss the slice is done (role order puts them side by side: most workgroups of a
+    // search on a code shard); otherwise no lane leaves early, see above
+    if (range && !__syncthreads_or(active ? 1 : 0)) return;
     const int n_live = active ? n_scanners : 0;   // an inactive token reads nothing and ends up with no candidates
     // ranged: the scanners of a code split the token's range misses hold no record (their workgroup may have left
     // without writing any) -- four scanners per split
